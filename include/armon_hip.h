@@ -1,0 +1,215 @@
+/*
+ * armon_hip.h — C ABI of libarmon_hip.so, the MI355X (gfx950) device backend for the
+ * direction-split hot path of Armon.jl.
+ *
+ * Every entry point below is what a Julia `ccall` (or any FFI) binds; no C++/torch types cross the
+ * boundary. The design follows the reference's own precedent for a C-ABI kernel library, the Kokkos
+ * extension: symbol = kernel name without `!` (ref src/generic_kernel.jl:616-620), iteration ranges
+ * passed first as plain structs (ref src/generic_kernel.jl:576-614, ext/ArmonKokkos.jl:10-30),
+ * limiter / test case as C int tags (ref ext/ArmonKokkos.jl:50-69), `flt_size`/`idx_size` sanity
+ * exports (ref ext/ArmonKokkos.jl:122-139), errors reported through a return code + message
+ * (ref ext/ArmonKokkos.jl:72-76 → `solver_error(:cpp, msg)`, ref src/utils.jl:108).
+ *
+ * Conventions
+ *  - All floating point data is fp64 (`double`) unless the symbol ends in `_f32`.
+ *  - All indices/strides are int64_t and 0-BASED on this side of the boundary (Julia subtracts 1).
+ *  - Arrays are flat device pointers of `(Nx+2g)*(Ny+2g)` elements, x-contiguous rows
+ *    (ref src/blocking/blocks.jl:18-50, src/blocking/blocking.jl:129-131). They are owned by the
+ *    caller; the library never frees or retains them beyond the stream-ordered call.
+ *  - Every kernel call is ASYNCHRONOUS on the context's stream and returns 0 on success or a
+ *    non-zero `armon_status`; `armon_hip_last_error()` gives the message. `armon_hip_sync`
+ *    implements `Base.wait(params)` (ref src/parameters.jl:1031-1038).
+ *  - One host thread per context.
+ */
+#ifndef ARMON_HIP_H
+#define ARMON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+typedef enum {
+    ARMON_OK = 0,
+    ARMON_ERR_INVALID_ARG = 1,   /* bad range / null pointer / unsupported option          */
+    ARMON_ERR_HIP = 2,           /* a HIP runtime call failed (message has hipGetErrorString) */
+    ARMON_ERR_NO_DEVICE = 3,     /* no usable gfx950 device                                   */
+    ARMON_ERR_INVALID_DT = 4     /* non finite or <= 0 time step (ref src/solver_state.jl:123) */
+} armon_status;
+
+/* ---- tags ------------------------------------------------------------------------------------ */
+/* ref ext/ArmonKokkos.jl:50-57 (limiter tags), src/limiters.jl:6-8 */
+enum { ARMON_LIMITER_NONE = 0, ARMON_LIMITER_MINMOD = 1, ARMON_LIMITER_SUPERBEE = 2 };
+/* ref ext/ArmonKokkos.jl:60-69 (test tags), src/tests.jl:5-11; DebugIndexes ref src/tests.jl:195 */
+enum { ARMON_TEST_SOD = 0, ARMON_TEST_SOD_Y = 1, ARMON_TEST_SOD_CIRC = 2, ARMON_TEST_BIZARRIUM = 3,
+       ARMON_TEST_SEDOV = 4, ARMON_TEST_DEBUG_INDEXES = 5 };
+/* ref src/riemann_schemes.jl:5-6 */
+enum { ARMON_SCHEME_GODUNOV = 0, ARMON_SCHEME_GAD = 1 };
+/* ref src/projection_schemes.jl:4-5 */
+enum { ARMON_PROJECTION_EULER = 0, ARMON_PROJECTION_EULER_2ND = 1 };
+/* EOS selected by the test case: ref src/kernels.jl:151-161 */
+enum { ARMON_EOS_PERFECT_GAS = 0, ARMON_EOS_BIZARRIUM = 1 };
+/* ref src/blocking/blocking.jl Axis / Side enums (Axis.X=1,Y=2; Side.Left=1,Right,Bottom,Top) */
+enum { ARMON_AXIS_X = 0, ARMON_AXIS_Y = 1 };
+enum { ARMON_SIDE_LEFT = 0, ARMON_SIDE_RIGHT = 1, ARMON_SIDE_BOTTOM = 2, ARMON_SIDE_TOP = 3 };
+enum { ARMON_MEMCPY_H2D = 1, ARMON_MEMCPY_D2H = 2, ARMON_MEMCPY_D2D = 3 };
+
+/*
+ * Iteration range = the reference's DomainRange (ref src/domain_ranges.jl:39-61), 0-based:
+ * cell index = col_start + j*col_step + row_start + i,  j in [0,col_len), i in [0,row_len).
+ * From Julia: col_start = first(range.col)-1, col_step = step(range.col), col_len = length(range.col),
+ *             row_start = first(range.row)-1, row_len = length(range.row).
+ */
+typedef struct {
+    int64_t col_start, col_step, col_len;
+    int64_t row_start, row_len;
+} armon_range;
+
+typedef struct armon_ctx armon_ctx;
+
+/* ---- sanity / context (ref ext/ArmonKokkos.jl:122-139, src/parameters.jl:751-802,921-926) ---- */
+int         armon_hip_flt_size(void);              /* sizeof(double) = 8                         */
+int         armon_hip_idx_size(void);              /* sizeof(int64_t) = 8                        */
+const char* armon_hip_version(void);
+const char* armon_hip_last_error(void);            /* thread-local message of the last failure   */
+int         armon_hip_device_count(int* count);
+
+/* `stream` = an existing hipStream_t to enqueue on (e.g. the caller's), or NULL to create one. */
+int armon_hip_init(int device_id, void* stream, armon_ctx** ctx);   /* create_device/init_backend */
+int armon_hip_destroy(armon_ctx* ctx);
+int armon_hip_sync(armon_ctx* ctx);                                  /* Base.wait(params)          */
+int armon_hip_device_memory_info(armon_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+int armon_hip_device_name(armon_ctx* ctx, char* buf, size_t buf_len);
+void* armon_hip_stream(armon_ctx* ctx);                              /* the hipStream_t in use     */
+
+/* device array type support: V{T,1}(undef, n) / copyto! (ref src/blocking/blocks.jl:36-44,121-143) */
+int armon_hip_malloc(armon_ctx* ctx, size_t bytes, void** ptr);
+int armon_hip_free(armon_ctx* ctx, void* ptr);
+int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind); /* async */
+int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes);             /* async */
+
+/* stream timers for benchmarks (hipEvent pairs on the context's stream) */
+int armon_hip_timer_start(armon_ctx* ctx);
+int armon_hip_timer_stop(armon_ctx* ctx, double* elapsed_ms);        /* synchronises on the stop event */
+
+/* ---- staged kernels: one per reference @generic_kernel ---------------------------------------- */
+
+/* perfect_gas_EOS!(params, data, range, γ)           ref src/kernels.jl:4-13, call :154 */
+int armon_hip_perfect_gas_EOS(armon_ctx*, armon_range, double gamma,
+        const double* rho, const double* E, const double* u, const double* v,
+        double* p, double* c, double* g);
+
+/* bizarrium_EOS!(params, data, range)                ref src/kernels.jl:16-55, call :160 */
+int armon_hip_bizarrium_EOS(armon_ctx*, armon_range,
+        const double* rho, const double* u, const double* v, const double* E,
+        double* p, double* c, double* g);
+
+/* acoustic!(params, data, range, s, uˢ_, pˢ_, uₐ)    ref src/riemann_schemes.jl:33-52 */
+int armon_hip_acoustic(armon_ctx*, armon_range, int64_t s, double* us, double* ps,
+        const double* rho, const double* ua, const double* p, const double* c);
+
+/* acoustic_GAD!(params, data, range, s, dt, dx, uₐ, lim)   ref src/riemann_schemes.jl:55-113 */
+int armon_hip_acoustic_GAD(armon_ctx*, armon_range, int64_t s, double dt, double dx,
+        double* us, double* ps,
+        const double* rho, const double* ua, const double* p, const double* c, int limiter);
+
+/* cell_update!(params, data, range, s, dx, dt, uₐ)   ref src/kernels.jl:58-68,217-223 */
+int armon_hip_cell_update(armon_ctx*, armon_range, int64_t s, double dx, double dt,
+        const double* us, const double* ps, double* rho, double* ua, double* E);
+
+/* advection_first_order!(params, data, range, s, dt, a_ρ, a_uρ, a_vρ, a_Eρ)
+ *                                                    ref src/projection_schemes.jl:62-89 */
+int armon_hip_advection_first_order(armon_ctx*, armon_range, int64_t s, double dt,
+        const double* us, const double* rho, const double* u, const double* v, const double* E,
+        double* adv_rho, double* adv_urho, double* adv_vrho, double* adv_Erho);
+
+/* advection_second_order!(params, data, range, s, dx, dt, a×4)
+ *                                                    ref src/projection_schemes.jl:15-20,92-135 */
+int armon_hip_advection_second_order(armon_ctx*, armon_range, int64_t s, double dx, double dt,
+        const double* us, const double* rho, const double* u, const double* v, const double* E,
+        double* adv_rho, double* adv_urho, double* adv_vrho, double* adv_Erho);
+
+/* euler_projection!(params, data, range, s, dx, dt, a×4)   ref src/projection_schemes.jl:23-52 */
+int armon_hip_euler_projection(armon_ctx*, armon_range, int64_t s, double dx, double dt,
+        const double* us, double* rho, double* u, double* v, double* E,
+        const double* adv_rho, const double* adv_urho, const double* adv_vrho, const double* adv_Erho);
+
+/* boundary_conditions!(params, data, range, bsize, axis, side, u_factor, v_factor)
+ * ref src/halo_exchange.jl:2-36. `range` = border_domain(bsize, side) (one strip of real cells);
+ * `incr` = ±stride_along(bsize, axis), signed towards the edge (ref :8-10); `nghost` = ghosts(bsize). */
+int armon_hip_boundary_conditions(armon_ctx*, armon_range, int64_t incr, int nghost,
+        double u_factor, double v_factor,
+        double* rho, double* u, double* v, double* p, double* c, double* g, double* E);
+
+/* pack_to_array!/unpack_from_array!(params, range, bsize, side, array, vars)
+ * ref src/halo_exchange.jl:187-216. `range` = border_domain / ghost_domain (single_strip=false);
+ * `face` = real_face_size(bsize, side); buffer index (i_g*face + i)*nvars + v with
+ * (i, i_g) = divrem(iter, nghost), iter = 0-based position in the range (row-major).
+ * `vars` = HOST array of `nvars` device pointers (comm_vars: ρ,u,v,E,p,c,g  ref src/blocking/blocks.jl:50). */
+int armon_hip_pack_to_array(armon_ctx*, armon_range, int nghost, int64_t face,
+        double* array, int nvars, const double* const* vars);
+int armon_hip_unpack_from_array(armon_ctx*, armon_range, int nghost, int64_t face,
+        const double* array, int nvars, double* const* vars);
+
+/* dtCFL_kernel(params, state, blk, Δx)::T            ref src/reductions.jl:2-110
+ * Min over `range` (real cells) of min(dx/max|u±c|, dy/max|v±c|). Two forms:
+ *  _async: result left in device memory `*result_dev` (one double), no host sync;
+ *  plain : synchronises and returns the value in `*result_host`. */
+int armon_hip_dtCFL_async(armon_ctx*, armon_range, double dx, double dy,
+        const double* u, const double* v, const double* c, double* result_dev);
+int armon_hip_dtCFL(armon_ctx*, armon_range, double dx, double dy,
+        const double* u, const double* v, const double* c, double* result_host);
+
+/* conservation_vars(params, blk)::(T,T)              ref src/reductions.jl:202-323
+ * out[0] = ds*Σρ, out[1] = ds*ΣρE over `range`; synchronises. */
+int armon_hip_conservation_vars(armon_ctx*, armon_range, double ds,
+        const double* rho, const double* E, double out_host[2]);
+
+/* init_test(params, data, range, global_pos, bsize, ΔX, vars_to_zero, test_case)
+ * ref src/kernels.jl:71-145,176-207, src/tests.jl:59-121.
+ * `range` = full domain (real+ghost); row_length = Nx+2g; global_pos = 0-based global index of the
+ * block's first real cell (ref src/kernels.jl:181-182); global_N = global grid (for DebugIndexes);
+ * sedov_r (ref src/tests.jl:15-19) is only read for ARMON_TEST_SEDOV. All 16 arrays are written. */
+typedef struct {
+    double *x, *y, *rho, *u, *v, *E, *p, *c, *g, *us, *ps, *work_1, *work_2, *work_3, *work_4, *mask;
+} armon_block_data;   /* ref src/blocking/blocks.jl:18-35 (BlockData) */
+
+int armon_hip_init_test(armon_ctx*, armon_range, int test, int64_t row_length, int64_t col_length,
+        int nghost, const int64_t global_pos[2], const int64_t global_N[2],
+        const double origin[2], const double dX[2], double sedov_r, const armon_block_data* data);
+
+/* ---- fused sweep: EOS → BC (in-tile mirror) → fluxes → cell update → advection → projection ---- */
+/* One call = one directional sweep of solver_cycle (ref src/solver.jl:300-316) over one block, reading
+ * (ρ,u,v,E) from `in` and writing them to `out` (ping-pong; `in` and `out` must not alias).
+ * Algorithmic traffic 64 B per real cell. Optionally materialises p (saved_vars, ref
+ * src/blocking/blocks.jl:49) and the per-cell CFL minimum for the next cycle. */
+typedef struct {
+    int32_t axis;            /* ARMON_AXIS_X / _Y                                               */
+    int32_t scheme;          /* ARMON_SCHEME_*                                                  */
+    int32_t limiter;         /* ARMON_LIMITER_*  (GAD only)                                     */
+    int32_t projection;      /* ARMON_PROJECTION_*                                              */
+    int32_t eos;             /* ARMON_EOS_*                                                     */
+    int32_t nghost;          /* ghost layers of the arrays (>= scheme·projection stencil)       */
+    int32_t bc_low, bc_high; /* 1: physical boundary on the low/high side of `axis` → mirror BC
+                                applied in-tile; 0: ghosts already hold neighbour data (halo)   */
+    int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to staged  */
+    int32_t reserved;
+    int64_t nx, ny;          /* real cells of the block                                         */
+    double  dt, dx;          /* sweep time step (current_dt·factor) and cell size along axis    */
+    double  gamma;           /* perfect gas only                                                */
+    double  u_factor_low, v_factor_low, u_factor_high, v_factor_high;   /* BC factors per side  */
+    const double *rho_in, *u_in, *v_in, *E_in;
+    double *rho_out, *u_out, *v_out, *E_out;
+    double *p_out;           /* nullable: EOS pressure of the PRE-sweep state (real cells)      */
+    double *c_out;           /* nullable: EOS sound speed of the PRE-sweep state (real cells)   */
+} armon_sweep_desc;
+
+int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARMON_HIP_H */
