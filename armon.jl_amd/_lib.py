@@ -1,0 +1,125 @@
+"""ctypes binding of libarmon_hip.so — the same C ABI a Julia ``ccall`` shim binds (include/armon_hip.h).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarmon_hip.so")
+
+FIELDS = ("x", "y", "rho", "u", "v", "E", "p", "c", "g", "us", "ps",
+          "work_1", "work_2", "work_3", "work_4", "mask")
+
+
+class SolverException(Exception):
+    """ref src/utils.jl:102-117 — ``category`` is :config, :time, :cpp ... in the reference."""
+
+    def __init__(self, category, msg):
+        super().__init__(f"{category}: {msg}")
+        self.category = category
+        self.msg = msg
+
+
+def solver_error(category, msg):
+    raise SolverException(category, msg)
+
+
+class Range(C.Structure):
+    """armon_range — 0-based DomainRange (ref src/domain_ranges.jl:39-61)."""
+    _fields_ = [("col_start", C.c_int64), ("col_step", C.c_int64), ("col_len", C.c_int64),
+                ("row_start", C.c_int64), ("row_len", C.c_int64)]
+
+    def __len__(self):
+        return self.col_len * self.row_len
+
+    def __repr__(self):
+        return (f"Range(col={self.col_start}:{self.col_step}:x{self.col_len}, "
+                f"row={self.row_start}+{self.row_len})")
+
+
+class BlockDataPtrs(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in FIELDS]
+
+
+class SweepDesc(C.Structure):
+    _fields_ = [("axis", C.c_int32), ("scheme", C.c_int32), ("limiter", C.c_int32),
+                ("projection", C.c_int32), ("eos", C.c_int32), ("nghost", C.c_int32),
+                ("bc_low", C.c_int32), ("bc_high", C.c_int32), ("exact", C.c_int32),
+                ("reserved", C.c_int32),
+                ("nx", C.c_int64), ("ny", C.c_int64),
+                ("dt", C.c_double), ("dx", C.c_double), ("gamma", C.c_double),
+                ("u_factor_low", C.c_double), ("v_factor_low", C.c_double),
+                ("u_factor_high", C.c_double), ("v_factor_high", C.c_double),
+                ("rho_in", C.c_void_p), ("u_in", C.c_void_p), ("v_in", C.c_void_p), ("E_in", C.c_void_p),
+                ("rho_out", C.c_void_p), ("u_out", C.c_void_p), ("v_out", C.c_void_p), ("E_out", C.c_void_p),
+                ("p_out", C.c_void_p), ("c_out", C.c_void_p)]
+
+
+_lib = None
+
+# name → (restype, argtypes); every symbol include/armon_hip.h declares
+_dp, _i64, _dbl, _ci, _vp = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p
+SIGNATURES = {
+    "armon_hip_flt_size": (_ci, []),
+    "armon_hip_idx_size": (_ci, []),
+    "armon_hip_version": (C.c_char_p, []),
+    "armon_hip_last_error": (C.c_char_p, []),
+    "armon_hip_device_count": (_ci, [C.POINTER(_ci)]),
+    "armon_hip_init": (_ci, [_ci, _vp, C.POINTER(_vp)]),
+    "armon_hip_destroy": (_ci, [_vp]),
+    "armon_hip_sync": (_ci, [_vp]),
+    "armon_hip_device_memory_info": (_ci, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "armon_hip_device_name": (_ci, [_vp, C.c_char_p, C.c_size_t]),
+    "armon_hip_stream": (_vp, [_vp]),
+    "armon_hip_malloc": (_ci, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "armon_hip_free": (_ci, [_vp, _vp]),
+    "armon_hip_memcpy": (_ci, [_vp, _vp, _vp, C.c_size_t, _ci]),
+    "armon_hip_memset": (_ci, [_vp, _vp, _ci, C.c_size_t]),
+    "armon_hip_timer_start": (_ci, [_vp]),
+    "armon_hip_timer_stop": (_ci, [_vp, C.POINTER(_dbl)]),
+    "armon_hip_perfect_gas_EOS": (_ci, [_vp, Range, _dbl] + [_dp] * 7),
+    "armon_hip_bizarrium_EOS": (_ci, [_vp, Range] + [_dp] * 7),
+    "armon_hip_acoustic": (_ci, [_vp, Range, _i64] + [_dp] * 6),
+    "armon_hip_acoustic_GAD": (_ci, [_vp, Range, _i64, _dbl, _dbl] + [_dp] * 6 + [_ci]),
+    "armon_hip_cell_update": (_ci, [_vp, Range, _i64, _dbl, _dbl] + [_dp] * 5),
+    "armon_hip_advection_first_order": (_ci, [_vp, Range, _i64, _dbl] + [_dp] * 9),
+    "armon_hip_advection_second_order": (_ci, [_vp, Range, _i64, _dbl, _dbl] + [_dp] * 9),
+    "armon_hip_euler_projection": (_ci, [_vp, Range, _i64, _dbl, _dbl] + [_dp] * 9),
+    "armon_hip_boundary_conditions": (_ci, [_vp, Range, _i64, _ci, _dbl, _dbl] + [_dp] * 7),
+    "armon_hip_pack_to_array": (_ci, [_vp, Range, _ci, _i64, _dp, _ci, C.POINTER(_dp)]),
+    "armon_hip_unpack_from_array": (_ci, [_vp, Range, _ci, _i64, _dp, _ci, C.POINTER(_dp)]),
+    "armon_hip_dtCFL_async": (_ci, [_vp, Range, _dbl, _dbl] + [_dp] * 4),
+    "armon_hip_dtCFL": (_ci, [_vp, Range, _dbl, _dbl] + [_dp] * 3 + [C.POINTER(_dbl)]),
+    "armon_hip_conservation_vars": (_ci, [_vp, Range, _dbl, _dp, _dp, C.POINTER(_dbl * 2)]),
+    "armon_hip_init_test": (_ci, [_vp, Range, _ci, _i64, _i64, _ci, C.POINTER(_i64 * 2),
+                                  C.POINTER(_i64 * 2), C.POINTER(_dbl * 2), C.POINTER(_dbl * 2),
+                                  _dbl, C.POINTER(BlockDataPtrs)]),
+    "armon_hip_sweep": (_ci, [_vp, C.POINTER(SweepDesc)]),
+}
+
+
+def lib():
+    """Load libarmon_hip.so (once) and declare every entry point. Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python armon.jl_amd/build.py` "
+                "(there is no CPU fallback for the device backend)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if L.armon_hip_flt_size() != 8 or L.armon_hip_idx_size() != 8:   # ref ext/ArmonKokkos.jl:122-139
+            raise RuntimeError("libarmon_hip.so: unexpected flt_size/idx_size")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    """Turn a non-zero status into SolverException(:cpp, msg) (ref ext/ArmonKokkos.jl:72-76)."""
+    if rc != 0:
+        msg = lib().armon_hip_last_error().decode(errors="replace")
+        raise SolverException("cpp" if rc != 4 else "time", f"[{rc}] {msg}")

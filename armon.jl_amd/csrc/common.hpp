@@ -1,0 +1,84 @@
+// common.hpp — context, error reporting and launch helpers shared by every translation unit of
+// libarmon_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/armon_hip.h"
+
+struct armon_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // scratch owned by the context (reduction partials, device scalars, pointer tables)
+    double* partials = nullptr;      // [partials_cap]
+    size_t partials_cap = 0;
+    double* scalars = nullptr;       // [16] device doubles: results of reductions
+    double* host_scalars = nullptr;  // [16] pinned host mirror
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int n_cu = 256;
+};
+
+namespace armon {
+
+void set_error(const char* fmt, ...);
+
+inline int fail_hip(hipError_t e, const char* what)
+{
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return ARMON_ERR_HIP;
+}
+
+#define ARMON_HIP_TRY(expr)                                             \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) return ::armon::fail_hip(e_, #expr);      \
+    } while (0)
+
+#define ARMON_REQUIRE(cond, ...)                                        \
+    do {                                                                \
+        if (!(cond)) {                                                  \
+            ::armon::set_error(__VA_ARGS__);                            \
+            return ARMON_ERR_INVALID_ARG;                               \
+        }                                                               \
+    } while (0)
+
+// Check the kernel launch itself (bad configuration shows up here, not at the next sync).
+inline int check_launch(const char* name)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", name, hipGetErrorString(e));
+        return ARMON_ERR_HIP;
+    }
+    return ARMON_OK;
+}
+
+inline bool range_ok(const armon_range& r)
+{
+    // row_start may be negative (ghost_domain of a first side shifts the row range below 1): only the
+    // first cell index has to be valid.
+    return r.col_len >= 0 && r.row_len >= 0 && r.col_start + r.row_start >= 0 && r.col_step >= 0;
+}
+inline bool range_empty(const armon_range& r) { return r.col_len == 0 || r.row_len == 0; }
+
+constexpr int kBlock = 256;  // 4 waves of 64
+
+// 2-D launch shape for a range: x covers a row (x-contiguous cells → coalesced), y covers rows.
+inline void range_grid(const armon_range& r, int cells_per_thread, dim3& grid, dim3& block)
+{
+    block = dim3(kBlock, 1, 1);
+    int64_t per_block = (int64_t)kBlock * cells_per_thread;
+    int64_t gx = (r.row_len + per_block - 1) / per_block;
+    int64_t gy = r.col_len < 65535 ? r.col_len : 65535;
+    grid = dim3((unsigned)gx, (unsigned)gy, 1);
+}
+
+int ensure_partials(armon_ctx* ctx, size_t n);
+
+}  // namespace armon

@@ -1,0 +1,204 @@
+// context.hip — context management, device memory and error reporting of libarmon_hip.so.
+// Mirrors the backend hooks of the reference: create_device / init_backend
+// (ref src/parameters.jl:751-778), device_array_type allocation + copyto!
+// (ref src/blocking/blocks.jl:36-44,121-143), Base.wait (ref src/parameters.jl:1031-1038),
+// device_memory_info (ref src/parameters.jl:921-926, ext/ArmonAMDGPU.jl:25-27).
+#include "common.hpp"
+
+namespace armon {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int ensure_partials(armon_ctx* ctx, size_t n)
+{
+    if (n <= ctx->partials_cap) return ARMON_OK;
+    // Grow only between kernels of the same stream: the old buffer may still be read by queued work.
+    ARMON_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->partials) ARMON_HIP_TRY(hipFree(ctx->partials));
+    ctx->partials = nullptr;
+    ctx->partials_cap = 0;
+    ARMON_HIP_TRY(hipMalloc((void**)&ctx->partials, n * sizeof(double)));
+    ctx->partials_cap = n;
+    return ARMON_OK;
+}
+
+}  // namespace armon
+
+using namespace armon;
+
+extern "C" {
+
+int armon_hip_flt_size(void) { return (int)sizeof(double); }
+int armon_hip_idx_size(void) { return (int)sizeof(int64_t); }
+const char* armon_hip_version(void) { return "armon_hip 0.1.0 (gfx950)"; }
+const char* armon_hip_last_error(void) { return g_error; }
+
+int armon_hip_device_count(int* count)
+{
+    ARMON_REQUIRE(count, "count is NULL");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip(e, "hipGetDeviceCount");
+    }
+    return ARMON_OK;
+}
+
+int armon_hip_init(int device_id, void* stream, armon_ctx** out)
+{
+    ARMON_REQUIRE(out, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_error("no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+        return ARMON_ERR_NO_DEVICE;
+    }
+    ARMON_REQUIRE(device_id >= 0 && device_id < n, "device_id %d out of range [0,%d)", device_id, n);
+    ARMON_HIP_TRY(hipSetDevice(device_id));
+
+    hipDeviceProp_t prop;
+    ARMON_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library holds gfx950 code objects only", device_id, prop.gcnArchName);
+        return ARMON_ERR_NO_DEVICE;
+    }
+
+    armon_ctx* ctx = new armon_ctx();
+    ctx->device = device_id;
+    ctx->n_cu = prop.multiProcessorCount;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->owns_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return fail_hip(e, "hipStreamCreate"); }
+        ctx->owns_stream = true;
+    }
+    if ((e = hipMalloc((void**)&ctx->scalars, 16 * sizeof(double))) != hipSuccess ||
+        (e = hipHostMalloc((void**)&ctx->host_scalars, 16 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) {
+        armon_hip_destroy(ctx);
+        return fail_hip(e, "context allocation");
+    }
+    int rc = ensure_partials(ctx, 8192);
+    if (rc != ARMON_OK) { armon_hip_destroy(ctx); return rc; }
+    *out = ctx;
+    return ARMON_OK;
+}
+
+int armon_hip_destroy(armon_ctx* ctx)
+{
+    if (!ctx) return ARMON_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->scalars) (void)hipFree(ctx->scalars);
+    if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ARMON_OK;
+}
+
+int armon_hip_sync(armon_ctx* ctx)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    ARMON_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ARMON_OK;
+}
+
+void* armon_hip_stream(armon_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int armon_hip_device_memory_info(armon_ctx* ctx, size_t* free_bytes, size_t* total_bytes)
+{
+    ARMON_REQUIRE(ctx && free_bytes && total_bytes, "NULL argument");
+    ARMON_HIP_TRY(hipSetDevice(ctx->device));
+    ARMON_HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return ARMON_OK;
+}
+
+int armon_hip_device_name(armon_ctx* ctx, char* buf, size_t buf_len)
+{
+    ARMON_REQUIRE(ctx && buf && buf_len > 0, "NULL argument");
+    hipDeviceProp_t prop;
+    ARMON_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return ARMON_OK;
+}
+
+int armon_hip_malloc(armon_ctx* ctx, size_t bytes, void** ptr)
+{
+    ARMON_REQUIRE(ctx && ptr, "NULL argument");
+    *ptr = nullptr;
+    if (bytes == 0) return ARMON_OK;
+    ARMON_HIP_TRY(hipSetDevice(ctx->device));
+    ARMON_HIP_TRY(hipMalloc(ptr, bytes));
+    return ARMON_OK;
+}
+
+int armon_hip_free(armon_ctx* ctx, void* ptr)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    if (!ptr) return ARMON_OK;
+    ARMON_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ARMON_HIP_TRY(hipFree(ptr));
+    return ARMON_OK;
+}
+
+int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    if (bytes == 0) return ARMON_OK;
+    ARMON_REQUIRE(dst && src, "NULL pointer in memcpy");
+    hipMemcpyKind k;
+    switch (kind) {
+    case ARMON_MEMCPY_H2D: k = hipMemcpyHostToDevice; break;
+    case ARMON_MEMCPY_D2H: k = hipMemcpyDeviceToHost; break;
+    case ARMON_MEMCPY_D2D: k = hipMemcpyDeviceToDevice; break;
+    default: ARMON_REQUIRE(false, "unknown memcpy kind %d", kind);
+    }
+    ARMON_HIP_TRY(hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
+    // Pageable host memory: the copy is staged, and the caller may reuse the host buffer at once.
+    if (k != hipMemcpyDeviceToDevice) ARMON_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ARMON_OK;
+}
+
+int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    if (bytes == 0) return ARMON_OK;
+    ARMON_REQUIRE(dst, "NULL pointer in memset");
+    ARMON_HIP_TRY(hipMemsetAsync(dst, byte_value, bytes, ctx->stream));
+    return ARMON_OK;
+}
+
+int armon_hip_timer_start(armon_ctx* ctx)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    ARMON_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    return ARMON_OK;
+}
+
+int armon_hip_timer_stop(armon_ctx* ctx, double* elapsed_ms)
+{
+    ARMON_REQUIRE(ctx && elapsed_ms, "NULL argument");
+    ARMON_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ARMON_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    float ms = 0.f;
+    ARMON_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    *elapsed_ms = (double)ms;
+    return ARMON_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""Device object and device array type of the HIP backend.
+
+Counterpart of the backend hooks of the reference: ``create_device(::Val{:ROCM})`` /
+``device_array_type`` / ``device_memory_info`` / ``Base.wait`` (ref src/parameters.jl:751-802,921-951,
+1031-1038; ext/ArmonAMDGPU.jl:9-27). The arrays are raw HBM allocations made through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class HIPDevice:
+    """One context = one GPU + one stream (ref ``params.device``)."""
+
+    def __init__(self, device_id=0, stream=None):
+        L = _lib.lib()
+        ctx = C.c_void_p()
+        check(L.armon_hip_init(int(device_id), C.c_void_p(stream) if stream else None, C.byref(ctx)))
+        self._L = L
+        self.ctx = ctx
+        self.device_id = int(device_id)
+
+    def close(self):
+        if self.ctx:
+            self._L.armon_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def wait(self):
+        """``Base.wait(params)``"""
+        check(self._L.armon_hip_sync(self.ctx))
+
+    def memory_info(self):
+        free, total = C.c_size_t(), C.c_size_t()
+        check(self._L.armon_hip_device_memory_info(self.ctx, C.byref(free), C.byref(total)))
+        return free.value, total.value
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(self._L.armon_hip_device_name(self.ctx, buf, 256))
+        return buf.value.decode()
+
+    @property
+    def stream(self):
+        return self._L.armon_hip_stream(self.ctx)
+
+    def timer_start(self):
+        check(self._L.armon_hip_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        check(self._L.armon_hip_timer_stop(self.ctx, C.byref(ms)))
+        return ms.value
+
+    # array constructors ------------------------------------------------------------------------
+    def empty(self, n, dtype=np.float64):
+        return DeviceArray(self, n, dtype)
+
+    def zeros(self, n, dtype=np.float64):
+        a = DeviceArray(self, n, dtype)
+        a.fill_bytes(0)
+        return a
+
+    def from_host(self, host):
+        host = np.ascontiguousarray(host)
+        a = DeviceArray(self, host.size, host.dtype)
+        a.copy_from_host(host)
+        return a
+
+
+class DeviceArray:
+    """Flat 1-D device vector: the ``V{T,1}(undef, n)`` of ref src/blocking/blocks.jl:36-44."""
+
+    def __init__(self, device, n, dtype=np.float64):
+        self.device = device
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = self.n * self.dtype.itemsize
+        p = C.c_void_p()
+        check(device._L.armon_hip_malloc(device.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def __len__(self):
+        return self.n
+
+    def free(self):
+        if self.ptr and self.device.ctx:
+            self.device._L.armon_hip_free(self.device.ctx, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def fill_bytes(self, byte):
+        check(self.device._L.armon_hip_memset(self.device.ctx, C.c_void_p(self.ptr), byte, self.nbytes))
+
+    def copy_from_host(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.size == self.n, (host.size, self.n)
+        check(self.device._L.armon_hip_memcpy(self.device.ctx, C.c_void_p(self.ptr),
+                                              host.ctypes.data_as(C.c_void_p), self.nbytes,
+                                              _lib_kind("H2D")))
+
+    def to_host(self, out=None):
+        if out is None:
+            out = np.empty(self.n, dtype=self.dtype)
+        assert out.size == self.n and out.dtype == self.dtype and out.flags["C_CONTIGUOUS"]
+        check(self.device._L.armon_hip_memcpy(self.device.ctx, out.ctypes.data_as(C.c_void_p),
+                                              C.c_void_p(self.ptr), self.nbytes, _lib_kind("D2H")))
+        return out
+
+    def copy_from_device(self, other):
+        assert other.nbytes == self.nbytes
+        check(self.device._L.armon_hip_memcpy(self.device.ctx, C.c_void_p(self.ptr),
+                                              C.c_void_p(other.ptr), self.nbytes, _lib_kind("D2D")))
+
+
+def _lib_kind(k):
+    return {"H2D": 1, "D2H": 2, "D2D": 3}[k]

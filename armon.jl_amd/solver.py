@@ -1,0 +1,407 @@
+"""Solver driver of the HIP backend: ``armon(params)``, ``time_loop``, ``solver_cycle`` and the dt state.
+
+Mirrors ref src/solver.jl:288-516 (synchronous cycle — the path a device backend uses),
+src/solver_state.jl:58-166 (GlobalTimeStep), src/axis_splitting.jl:24-46, and the per-block kernel
+wrappers of src/kernels.jl:151-230, src/riemann_schemes.jl:46-120, src/projection_schemes.jl:44-157,
+src/halo_exchange.jl:32-36,286-368, src/reductions.jl:89-110,164-199,301-323. Every kernel call goes
+through the C ABI of libarmon_hip.so; nothing here computes on the host.
+"""
+import ctypes as C
+import math
+import time as _time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import BlockDataPtrs, FIELDS, SweepDesc, check, solver_error
+from .blocking import Axis, Side, first_side, last_side, sides_along
+from .parameters import LIMITERS, PROC_NULL, PROJECTIONS, SCHEMES
+
+MAIN_VARS = ("x", "y", "rho", "u", "v", "E", "p", "c", "g", "us", "ps")   # ref src/blocking/blocks.jl:47
+SAVED_VARS = ("x", "y", "rho", "u", "v", "p")                              # ref :49
+COMM_VARS = ("rho", "u", "v", "E", "p", "c", "g")                          # ref :50
+STATE_VARS = ("rho", "u", "v", "E")
+
+
+@dataclass
+class SolverStats:   # ref src/solver.jl:13-23
+    final_time: float
+    last_dt: float
+    cycles: int
+    solve_time: float          # seconds
+    cell_count: int
+    giga_cells_per_sec: float
+    data: object = None
+    timer: object = None
+    grid_log: object = None
+
+    def __str__(self):   # ref src/solver.jl:26-35
+        return (f"Solver stats:\n - final time:  {self.final_time}\n - last Δt:     {self.last_dt}\n"
+                f" - cycles:      {self.cycles}\n - performance: {self.giga_cells_per_sec} ×10⁹ cell-cycles/sec "
+                f"({self.solve_time} sec, {self.cell_count} cells)")
+
+
+class GlobalTimeStep:
+    """ref src/solver_state.jl:30-166 — cycle/time/dt with the reference's one-cycle lag."""
+
+    def __init__(self, params):
+        self.params = params
+        self.reset()
+
+    def reset(self):   # ref :58-68
+        p = self.params
+        self.cycle = 0
+        self.time = 0.
+        self.current_dt = p.Dt if p.cst_dt else 0.
+        self.next_cycle_dt = math.inf
+
+    def update_dt(self, new_dt):
+        """ref update_dt!, :102-142 (``new_dt`` = global minimum of the local CFL time steps)."""
+        p = self.params
+        previous_dt = self.current_dt
+        if not math.isfinite(new_dt) or new_dt <= 0:
+            solver_error("time", f"Invalid time step for cycle {self.cycle}: {new_dt}")
+        elif previous_dt == 0:
+            new_dt = p.cfl * new_dt
+        else:
+            new_dt = min(p.cfl * new_dt, 1.05 * previous_dt)
+        self.next_cycle_dt = new_dt
+        if self.current_dt == 0:
+            self.current_dt = self.next_cycle_dt
+
+    def next_cycle(self):
+        """ref next_cycle!, :145-166"""
+        p = self.params
+        self.cycle += 1
+        self.time += self.current_dt
+        if p.cst_dt:
+            self.current_dt = self.next_cycle_dt = p.Dt
+            return
+        self.current_dt = self.next_cycle_dt
+        self.next_cycle_dt = math.inf
+
+
+def split_axes(splitting, cycle):
+    """ref src/axis_splitting.jl:24-46 → sequence of (axis, dt_factor)."""
+    even = cycle % 2 == 0
+    if splitting == "Sequential":
+        return ((Axis.X, 1.0), (Axis.Y, 1.0))
+    if splitting in ("Godunov", "SequentialSym"):
+        return ((Axis.X, 1.0), (Axis.Y, 1.0)) if even else ((Axis.Y, 1.0), (Axis.X, 1.0))
+    if splitting == "Strang":
+        return (((Axis.X, 0.5), (Axis.Y, 1.0), (Axis.X, 0.5)) if even
+                else ((Axis.Y, 0.5), (Axis.X, 1.0), (Axis.Y, 0.5)))
+    if splitting == "X_only":
+        return ((Axis.X, 1.0),)
+    if splitting == "Y_only":
+        return ((Axis.Y, 1.0),)
+    solver_error("config", f"Unknown splitting method: '{splitting}'")
+
+
+class BlockGrid:
+    """One block per GPU (ref BlockGrid with use_cache_blocking=false, src/blocking/block_grid.jl:352-355):
+    the 16 ``BlockData`` vectors (ref src/blocking/blocks.jl:18-44) in HBM, plus the 4 ping-pong state
+    vectors the fused sweep writes to."""
+
+    def __init__(self, params):
+        self.params = params
+        self.size = params.block_size
+        dev = params.device
+        n = self.size.n_cells
+        self.data = {f: dev.empty(n) for f in FIELDS}
+        self.alt = {f: dev.empty(n) for f in STATE_VARS} if params.use_fused_sweep else None
+        self.global_dt = GlobalTimeStep(params)
+        self.dt_scalar = dev.zeros(2)          # device scalar(s) written by the fused dt reduction
+        self.comm = None                       # set by halo_exchange.setup when use_MPI
+
+    def ptr(self, name):
+        return C.c_void_p(self.data[name].ptr)
+
+    def block_data_ptrs(self):
+        bd = BlockDataPtrs()
+        for f in FIELDS:
+            setattr(bd, f, self.data[f].ptr)
+        return bd
+
+    def swap_state(self):
+        """After a fused sweep the fresh state lives in ``alt``: exchange the roles."""
+        for f in STATE_VARS:
+            self.data[f], self.alt[f] = self.alt[f], self.data[f]
+
+    def device_to_host(self, names=MAIN_VARS):
+        """ref device_to_host!, src/blocking/blocks.jl:121-131"""
+        self.params.wait()
+        return {f: self.data[f].to_host() for f in names}
+
+    def host_to_device(self, host):
+        for f, a in host.items():
+            self.data[f].copy_from_host(a)
+
+    def real_view(self, a):
+        g = self.size.ghosts
+        nx, ny = self.size.real_size
+        return a.reshape(self.size.size[1], self.size.size[0])[g:g + ny, g:g + nx]
+
+    def memory_required(self):
+        n = self.size.n_cells * 8
+        return n * (16 + (4 if self.alt else 0))
+
+
+# ---- per-block kernel wrappers -----------------------------------------------------------------
+
+def _L():
+    return _lib.lib()
+
+
+def _range(params, corners):
+    return params.block_size.domain_range(*corners).to_c()
+
+
+def init_test(params, grid):
+    """ref src/kernels.jl:176-207"""
+    bs = params.block_size
+    full = params.steps_ranges[Axis.X].full_domain
+    gpos = (C.c_int64 * 2)(params.N_origin[0] - 1, params.N_origin[1] - 1)
+    gN = (C.c_int64 * 2)(*params.global_grid)
+    origin = (C.c_double * 2)(*params.origin)
+    dX = (C.c_double * 2)(params.domain_size[0] / params.global_grid[0],
+                          params.domain_size[1] / params.global_grid[1])
+    bd = grid.block_data_ptrs()
+    check(_L().armon_hip_init_test(params.device.ctx, _range(params, full), params.test.tag,
+                                   bs.size[0], bs.size[1], bs.ghosts, C.byref(gpos), C.byref(gN),
+                                   C.byref(origin), C.byref(dX), params.test.r, C.byref(bd)))
+
+
+def update_EOS(params, grid, axis=Axis.X):
+    """ref src/kernels.jl:151-173"""
+    r = _range(params, params.steps_ranges[axis].EOS)
+    p = grid.ptr
+    if params.test.eos == "bizarrium":
+        check(_L().armon_hip_bizarrium_EOS(params.device.ctx, r, p("rho"), p("u"), p("v"), p("E"),
+                                           p("p"), p("c"), p("g")))
+    else:
+        check(_L().armon_hip_perfect_gas_EOS(params.device.ctx, r, params.test.gamma, p("rho"), p("E"),
+                                             p("u"), p("v"), p("p"), p("c"), p("g")))
+
+
+def boundary_conditions(params, grid, axis, side):
+    """ref src/halo_exchange.jl:32-36"""
+    bs = params.block_size
+    uf, vf = params.test.boundary_condition(side)
+    domain = bs.border_domain(side).to_c()
+    incr = bs.stride_along(axis)
+    if side in (Side.Left, Side.Bottom):
+        incr = -incr
+    p = grid.ptr
+    check(_L().armon_hip_boundary_conditions(params.device.ctx, domain, incr, bs.ghosts, uf, vf,
+                                             p("rho"), p("u"), p("v"), p("p"), p("c"), p("g"), p("E")))
+
+
+def block_ghost_exchange(params, grid, axis):
+    """ref src/halo_exchange.jl:286-368: physical boundary → mirror BC; process boundary → exchange."""
+    remote = [s for s in sides_along(axis) if params.neighbours[s] != PROC_NULL]
+    if remote:
+        from .halo_exchange import exchange_sides
+        exchange_sides(params, grid, axis, remote, COMM_VARS)
+    for side in sides_along(axis):
+        if params.neighbours[side] == PROC_NULL:
+            boundary_conditions(params, grid, axis, side)
+
+
+def numerical_fluxes(params, grid, axis, dt, dx):
+    """ref src/riemann_schemes.jl:46-52,107-113"""
+    r = _range(params, params.steps_ranges[axis].fluxes)
+    s = params.block_size.stride_along(axis)
+    p = grid.ptr
+    ua = p("u") if axis == Axis.X else p("v")
+    if params.riemann_scheme == "GAD":
+        check(_L().armon_hip_acoustic_GAD(params.device.ctx, r, s, dt, dx, p("us"), p("ps"), p("rho"), ua,
+                                          p("p"), p("c"), LIMITERS[params.riemann_limiter]))
+    else:
+        check(_L().armon_hip_acoustic(params.device.ctx, r, s, p("us"), p("ps"), p("rho"), ua, p("p"), p("c")))
+
+
+def cell_update(params, grid, axis, dt, dx):
+    """ref src/kernels.jl:217-223"""
+    r = _range(params, params.steps_ranges[axis].cell_update)
+    s = params.block_size.stride_along(axis)
+    p = grid.ptr
+    ua = p("u") if axis == Axis.X else p("v")
+    check(_L().armon_hip_cell_update(params.device.ctx, r, s, dx, dt, p("us"), p("ps"), p("rho"), ua, p("E")))
+
+
+def projection_remap(params, grid, axis, dt, dx):
+    """ref src/projection_schemes.jl:44-157: advection_fluxes! then euler_projection!"""
+    s = params.block_size.stride_along(axis)
+    p = grid.ptr
+    ra = _range(params, params.steps_ranges[axis].advection)
+    w = (p("work_1"), p("work_2"), p("work_3"), p("work_4"))
+    if params.projection_scheme == "euler_2nd":
+        check(_L().armon_hip_advection_second_order(params.device.ctx, ra, s, dx, dt, p("us"), p("rho"),
+                                                    p("u"), p("v"), p("E"), *w))
+    else:
+        check(_L().armon_hip_advection_first_order(params.device.ctx, ra, s, dt, p("us"), p("rho"),
+                                                   p("u"), p("v"), p("E"), *w))
+    rp = _range(params, params.steps_ranges[axis].projection)
+    check(_L().armon_hip_euler_projection(params.device.ctx, rp, s, dx, dt, p("us"), p("rho"), p("u"),
+                                          p("v"), p("E"), *w))
+
+
+def local_time_step(params, grid):
+    """ref src/reductions.jl:89-110 (dx, dy are the GLOBAL cell sizes, :92)"""
+    r = _range(params, params.steps_ranges[Axis.X].real_domain)
+    dx = params.domain_size[0] / params.global_grid[0]
+    dy = params.domain_size[1] / params.global_grid[1]
+    out = C.c_double()
+    p = grid.ptr
+    check(_L().armon_hip_dtCFL(params.device.ctx, r, dx, dy, p("u"), p("v"), p("c"), C.byref(out)))
+    return out.value
+
+
+def conservation_vars(params, grid):
+    """ref src/reductions.jl:262-323 → (total_mass, total_energy), summed over ranks when use_MPI"""
+    r = _range(params, params.steps_ranges[Axis.X].real_domain)
+    ds = (params.domain_size[0] / params.global_grid[0]) * (params.domain_size[1] / params.global_grid[1])
+    out = (C.c_double * 2)()
+    check(_L().armon_hip_conservation_vars(params.device.ctx, r, ds, grid.ptr("rho"), grid.ptr("E"), C.byref(out)))
+    mass, energy = out[0], out[1]
+    if params.use_MPI:
+        from .halo_exchange import allreduce_sum
+        mass, energy = allreduce_sum(params, (mass, energy))
+    return mass, energy
+
+
+def global_min(params, local_dt):
+    """MPI_Iallreduce(MIN) of ref src/solver_state.jl:107-111, src/utils.jl:126-143"""
+    if params.use_MPI:
+        from .halo_exchange import allreduce_min
+        return allreduce_min(params, local_dt)
+    return local_dt
+
+
+# ---- fused sweep -----------------------------------------------------------------------------------
+
+def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False):
+    """One directional sweep as a single kernel launch (armon_hip_sweep). The halo cells of process
+    boundaries must already hold the neighbour's (ρ,u,v,E)."""
+    d = SweepDesc()
+    d.axis = 0 if axis == Axis.X else 1
+    d.scheme = SCHEMES[params.riemann_scheme]
+    d.limiter = LIMITERS[params.riemann_limiter]
+    d.projection = PROJECTIONS[params.projection_scheme]
+    d.eos = 1 if params.test.eos == "bizarrium" else 0
+    d.nghost = params.nghost
+    lo, hi = first_side(axis), last_side(axis)
+    d.bc_low = int(params.neighbours[lo] == PROC_NULL)
+    d.bc_high = int(params.neighbours[hi] == PROC_NULL)
+    d.exact = int(params.exact_arithmetic)
+    d.nx, d.ny = params.N
+    d.dt, d.dx, d.gamma = dt, dx, params.test.gamma
+    d.u_factor_low, d.v_factor_low = params.test.boundary_condition(lo)
+    d.u_factor_high, d.v_factor_high = params.test.boundary_condition(hi)
+    d.rho_in, d.u_in, d.v_in, d.E_in = (grid.data[f].ptr for f in STATE_VARS)
+    d.rho_out, d.u_out, d.v_out, d.E_out = (grid.alt[f].ptr for f in STATE_VARS)
+    d.p_out = grid.data["p"].ptr if emit_p else None
+    d.c_out = grid.data["c"].ptr if emit_c else None
+    check(_L().armon_hip_sweep(params.device.ctx, C.byref(d)))
+    grid.swap_state()
+
+
+# ---- cycle / time loop ---------------------------------------------------------------------------------
+
+def next_time_step(params, grid):
+    """ref src/reductions.jl:164-199 (grid form)"""
+    gdt = grid.global_dt
+    if params.cst_dt:
+        return
+    local_dt = local_time_step(params, grid)
+    gdt.update_dt(global_min(params, local_dt))
+
+
+def solver_cycle(params, grid):
+    """ref src/solver.jl:288-320"""
+    gdt = grid.global_dt
+    if gdt.cycle == 0:
+        update_EOS(params, grid)
+    next_time_step(params, grid)
+    sweeps = split_axes(params.axis_splitting, gdt.cycle)
+    for k, (axis, dt_factor) in enumerate(sweeps):
+        # update_solver_state!: ref src/solver_state.jl:339-345
+        i_ax = int(axis) - 1
+        dx = params.domain_size[i_ax] / params.global_grid[i_ax]
+        dt = gdt.current_dt * dt_factor
+        if params.use_fused_sweep:
+            if params.use_MPI:
+                from .halo_exchange import exchange_state_halo
+                exchange_state_halo(params, grid, axis)
+            # p and c of the pre-sweep state are what the reference leaves in memory after the last
+            # sweep of a cycle (ref SURVEY §3.4): materialise them there only.
+            last = k == len(sweeps) - 1
+            fused_sweep(params, grid, axis, dt, dx, emit_p=last, emit_c=last)
+        else:
+            update_EOS(params, grid, axis)
+            block_ghost_exchange(params, grid, axis)
+            numerical_fluxes(params, grid, axis, dt, dx)
+            cell_update(params, grid, axis, dt, dx)
+            projection_remap(params, grid, axis, dt, dx)
+
+
+def time_loop(params, grid):
+    """ref src/solver.jl:323-403 → (time, dt, cycles, cells_per_ns, solve_time_ns)"""
+    grid.global_dt.reset()
+    gdt = grid.global_dt
+    params.wait()
+    t1 = _time.perf_counter_ns()
+    while gdt.time < params.maxtime and gdt.cycle < params.maxcycle:
+        solver_cycle(params, grid)
+        gdt.next_cycle()
+        if params.silent <= 1:
+            params.wait()
+            mass, energy = conservation_vars(params, grid)
+            if params.is_root:
+                dM = abs(params.initial_mass - mass) / params.initial_mass * 100
+                dE = abs(params.initial_energy - energy) / params.initial_energy * 100
+                print(f"Cycle {gdt.cycle:4d}: dt = {gdt.current_dt:.18f}, t = {gdt.time:.18f}, "
+                      f"|ΔM| = {dM:#8.6g}%, |ΔE| = {dE:#8.6g}%")
+    params.wait()   # "Last fence"
+    t2 = _time.perf_counter_ns()
+    solve_time = t2 - t1
+    cells = params.N[0] * params.N[1]
+    grind_time = solve_time / max(gdt.cycle * cells, 1)
+    if params.is_root and params.silent < 3:
+        print(" ")
+        print(f"Total time:  {solve_time / 1e9:.5f} sec")
+        print(f"Grind time:  {grind_time / 1e3:.5f} µs/cell/cycle")
+        print(f"Cells/sec:   {1 / grind_time * 1e3:.5f} Mega cells/sec")
+        print(f"Cycles:      {gdt.cycle}")
+        print(f"Last cycle:  {gdt.time:.18f} sec, Δt={gdt.current_dt:.18f} sec")
+    return gdt.time, gdt.current_dt, gdt.cycle, 1 / grind_time, solve_time
+
+
+def armon(params):
+    """ref src/solver.jl:411-516 — main entry point, returns SolverStats."""
+    if params.is_root and params.silent < 3:
+        print(params)
+    grid = BlockGrid(params)
+    if params.use_MPI:
+        from .halo_exchange import setup
+        setup(params, grid)
+    init_test(params, grid)
+    if params.check_result or params.silent <= 1:
+        params.initial_mass, params.initial_energy = conservation_vars(params, grid)
+    final_time, dt, cycles, cells_per_ns, solve_time = time_loop(params, grid)
+    if params.check_result and params.test.conservative:
+        mass, energy = conservation_vars(params, grid)
+        if params.is_root:
+            dM = abs(params.initial_mass - mass)
+            dE = abs(params.initial_energy - energy)
+            if not (dM <= 1e-12 and dE <= 1e-12):   # ref src/solver.jl:484-501 (comparison_tolerance)
+                solver_error("check", f"mass or energy are not conserved: |ΔM| = {dM}, |ΔE| = {dE}")
+    if params.write_output:
+        from .io import write_sub_domain_file
+        write_sub_domain_file(params, grid, params.output_file)
+    stats = SolverStats(final_time, dt, cycles, solve_time / 1e9, params.N[0] * params.N[1], cells_per_ns)
+    if params.return_data:
+        stats.data = grid
+    return stats

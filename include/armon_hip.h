@@ -27,6 +27,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#if defined(ARMON_BUILDING_LIB)
+#define ARMON_API __attribute__((visibility("default")))
+#else
+#define ARMON_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -71,76 +77,76 @@ typedef struct {
 typedef struct armon_ctx armon_ctx;
 
 /* ---- sanity / context (ref ext/ArmonKokkos.jl:122-139, src/parameters.jl:751-802,921-926) ---- */
-int         armon_hip_flt_size(void);              /* sizeof(double) = 8                         */
-int         armon_hip_idx_size(void);              /* sizeof(int64_t) = 8                        */
-const char* armon_hip_version(void);
-const char* armon_hip_last_error(void);            /* thread-local message of the last failure   */
-int         armon_hip_device_count(int* count);
+ARMON_API int         armon_hip_flt_size(void);              /* sizeof(double) = 8                         */
+ARMON_API int         armon_hip_idx_size(void);              /* sizeof(int64_t) = 8                        */
+ARMON_API const char* armon_hip_version(void);
+ARMON_API const char* armon_hip_last_error(void);            /* thread-local message of the last failure   */
+ARMON_API int         armon_hip_device_count(int* count);
 
 /* `stream` = an existing hipStream_t to enqueue on (e.g. the caller's), or NULL to create one. */
-int armon_hip_init(int device_id, void* stream, armon_ctx** ctx);   /* create_device/init_backend */
-int armon_hip_destroy(armon_ctx* ctx);
-int armon_hip_sync(armon_ctx* ctx);                                  /* Base.wait(params)          */
-int armon_hip_device_memory_info(armon_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
-int armon_hip_device_name(armon_ctx* ctx, char* buf, size_t buf_len);
-void* armon_hip_stream(armon_ctx* ctx);                              /* the hipStream_t in use     */
+ARMON_API int armon_hip_init(int device_id, void* stream, armon_ctx** ctx);   /* create_device/init_backend */
+ARMON_API int armon_hip_destroy(armon_ctx* ctx);
+ARMON_API int armon_hip_sync(armon_ctx* ctx);                                  /* Base.wait(params)          */
+ARMON_API int armon_hip_device_memory_info(armon_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+ARMON_API int armon_hip_device_name(armon_ctx* ctx, char* buf, size_t buf_len);
+ARMON_API void* armon_hip_stream(armon_ctx* ctx);                              /* the hipStream_t in use     */
 
 /* device array type support: V{T,1}(undef, n) / copyto! (ref src/blocking/blocks.jl:36-44,121-143) */
-int armon_hip_malloc(armon_ctx* ctx, size_t bytes, void** ptr);
-int armon_hip_free(armon_ctx* ctx, void* ptr);
-int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind); /* async */
-int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes);             /* async */
+ARMON_API int armon_hip_malloc(armon_ctx* ctx, size_t bytes, void** ptr);
+ARMON_API int armon_hip_free(armon_ctx* ctx, void* ptr);
+ARMON_API int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind); /* async */
+ARMON_API int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes);             /* async */
 
 /* stream timers for benchmarks (hipEvent pairs on the context's stream) */
-int armon_hip_timer_start(armon_ctx* ctx);
-int armon_hip_timer_stop(armon_ctx* ctx, double* elapsed_ms);        /* synchronises on the stop event */
+ARMON_API int armon_hip_timer_start(armon_ctx* ctx);
+ARMON_API int armon_hip_timer_stop(armon_ctx* ctx, double* elapsed_ms);        /* synchronises on the stop event */
 
 /* ---- staged kernels: one per reference @generic_kernel ---------------------------------------- */
 
 /* perfect_gas_EOS!(params, data, range, γ)           ref src/kernels.jl:4-13, call :154 */
-int armon_hip_perfect_gas_EOS(armon_ctx*, armon_range, double gamma,
+ARMON_API int armon_hip_perfect_gas_EOS(armon_ctx*, armon_range, double gamma,
         const double* rho, const double* E, const double* u, const double* v,
         double* p, double* c, double* g);
 
 /* bizarrium_EOS!(params, data, range)                ref src/kernels.jl:16-55, call :160 */
-int armon_hip_bizarrium_EOS(armon_ctx*, armon_range,
+ARMON_API int armon_hip_bizarrium_EOS(armon_ctx*, armon_range,
         const double* rho, const double* u, const double* v, const double* E,
         double* p, double* c, double* g);
 
 /* acoustic!(params, data, range, s, uˢ_, pˢ_, uₐ)    ref src/riemann_schemes.jl:33-52 */
-int armon_hip_acoustic(armon_ctx*, armon_range, int64_t s, double* us, double* ps,
+ARMON_API int armon_hip_acoustic(armon_ctx*, armon_range, int64_t s, double* us, double* ps,
         const double* rho, const double* ua, const double* p, const double* c);
 
 /* acoustic_GAD!(params, data, range, s, dt, dx, uₐ, lim)   ref src/riemann_schemes.jl:55-113 */
-int armon_hip_acoustic_GAD(armon_ctx*, armon_range, int64_t s, double dt, double dx,
+ARMON_API int armon_hip_acoustic_GAD(armon_ctx*, armon_range, int64_t s, double dt, double dx,
         double* us, double* ps,
         const double* rho, const double* ua, const double* p, const double* c, int limiter);
 
 /* cell_update!(params, data, range, s, dx, dt, uₐ)   ref src/kernels.jl:58-68,217-223 */
-int armon_hip_cell_update(armon_ctx*, armon_range, int64_t s, double dx, double dt,
+ARMON_API int armon_hip_cell_update(armon_ctx*, armon_range, int64_t s, double dx, double dt,
         const double* us, const double* ps, double* rho, double* ua, double* E);
 
 /* advection_first_order!(params, data, range, s, dt, a_ρ, a_uρ, a_vρ, a_Eρ)
  *                                                    ref src/projection_schemes.jl:62-89 */
-int armon_hip_advection_first_order(armon_ctx*, armon_range, int64_t s, double dt,
+ARMON_API int armon_hip_advection_first_order(armon_ctx*, armon_range, int64_t s, double dt,
         const double* us, const double* rho, const double* u, const double* v, const double* E,
         double* adv_rho, double* adv_urho, double* adv_vrho, double* adv_Erho);
 
 /* advection_second_order!(params, data, range, s, dx, dt, a×4)
  *                                                    ref src/projection_schemes.jl:15-20,92-135 */
-int armon_hip_advection_second_order(armon_ctx*, armon_range, int64_t s, double dx, double dt,
+ARMON_API int armon_hip_advection_second_order(armon_ctx*, armon_range, int64_t s, double dx, double dt,
         const double* us, const double* rho, const double* u, const double* v, const double* E,
         double* adv_rho, double* adv_urho, double* adv_vrho, double* adv_Erho);
 
 /* euler_projection!(params, data, range, s, dx, dt, a×4)   ref src/projection_schemes.jl:23-52 */
-int armon_hip_euler_projection(armon_ctx*, armon_range, int64_t s, double dx, double dt,
+ARMON_API int armon_hip_euler_projection(armon_ctx*, armon_range, int64_t s, double dx, double dt,
         const double* us, double* rho, double* u, double* v, double* E,
         const double* adv_rho, const double* adv_urho, const double* adv_vrho, const double* adv_Erho);
 
 /* boundary_conditions!(params, data, range, bsize, axis, side, u_factor, v_factor)
  * ref src/halo_exchange.jl:2-36. `range` = border_domain(bsize, side) (one strip of real cells);
  * `incr` = ±stride_along(bsize, axis), signed towards the edge (ref :8-10); `nghost` = ghosts(bsize). */
-int armon_hip_boundary_conditions(armon_ctx*, armon_range, int64_t incr, int nghost,
+ARMON_API int armon_hip_boundary_conditions(armon_ctx*, armon_range, int64_t incr, int nghost,
         double u_factor, double v_factor,
         double* rho, double* u, double* v, double* p, double* c, double* g, double* E);
 
@@ -149,23 +155,23 @@ int armon_hip_boundary_conditions(armon_ctx*, armon_range, int64_t incr, int ngh
  * `face` = real_face_size(bsize, side); buffer index (i_g*face + i)*nvars + v with
  * (i, i_g) = divrem(iter, nghost), iter = 0-based position in the range (row-major).
  * `vars` = HOST array of `nvars` device pointers (comm_vars: ρ,u,v,E,p,c,g  ref src/blocking/blocks.jl:50). */
-int armon_hip_pack_to_array(armon_ctx*, armon_range, int nghost, int64_t face,
+ARMON_API int armon_hip_pack_to_array(armon_ctx*, armon_range, int nghost, int64_t face,
         double* array, int nvars, const double* const* vars);
-int armon_hip_unpack_from_array(armon_ctx*, armon_range, int nghost, int64_t face,
+ARMON_API int armon_hip_unpack_from_array(armon_ctx*, armon_range, int nghost, int64_t face,
         const double* array, int nvars, double* const* vars);
 
 /* dtCFL_kernel(params, state, blk, Δx)::T            ref src/reductions.jl:2-110
  * Min over `range` (real cells) of min(dx/max|u±c|, dy/max|v±c|). Two forms:
  *  _async: result left in device memory `*result_dev` (one double), no host sync;
  *  plain : synchronises and returns the value in `*result_host`. */
-int armon_hip_dtCFL_async(armon_ctx*, armon_range, double dx, double dy,
+ARMON_API int armon_hip_dtCFL_async(armon_ctx*, armon_range, double dx, double dy,
         const double* u, const double* v, const double* c, double* result_dev);
-int armon_hip_dtCFL(armon_ctx*, armon_range, double dx, double dy,
+ARMON_API int armon_hip_dtCFL(armon_ctx*, armon_range, double dx, double dy,
         const double* u, const double* v, const double* c, double* result_host);
 
 /* conservation_vars(params, blk)::(T,T)              ref src/reductions.jl:202-323
  * out[0] = ds*Σρ, out[1] = ds*ΣρE over `range`; synchronises. */
-int armon_hip_conservation_vars(armon_ctx*, armon_range, double ds,
+ARMON_API int armon_hip_conservation_vars(armon_ctx*, armon_range, double ds,
         const double* rho, const double* E, double out_host[2]);
 
 /* init_test(params, data, range, global_pos, bsize, ΔX, vars_to_zero, test_case)
@@ -177,7 +183,7 @@ typedef struct {
     double *x, *y, *rho, *u, *v, *E, *p, *c, *g, *us, *ps, *work_1, *work_2, *work_3, *work_4, *mask;
 } armon_block_data;   /* ref src/blocking/blocks.jl:18-35 (BlockData) */
 
-int armon_hip_init_test(armon_ctx*, armon_range, int test, int64_t row_length, int64_t col_length,
+ARMON_API int armon_hip_init_test(armon_ctx*, armon_range, int test, int64_t row_length, int64_t col_length,
         int nghost, const int64_t global_pos[2], const int64_t global_N[2],
         const double origin[2], const double dX[2], double sedov_r, const armon_block_data* data);
 
@@ -207,7 +213,7 @@ typedef struct {
     double *c_out;           /* nullable: EOS sound speed of the PRE-sweep state (real cells)   */
 } armon_sweep_desc;
 
-int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
+ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
 
 #ifdef __cplusplus
 }

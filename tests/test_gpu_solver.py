@@ -1,0 +1,151 @@
+"""End-to-end GPU parity: ``armon(params)`` through the C ABI against the reference's golden results
+and against the CPU oracle (bit-exact in exact-arithmetic mode), plus the reference's property tests
+(conservation, axis invariance, ghost garbage — ref test/conservation.jl, test/convergence.jl)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+G = 4
+
+
+def isapprox_count(a, b, atol=1e-13, rtol=4 * EPS):
+    return int((np.abs(a - b) > np.maximum(atol, rtol * np.maximum(np.abs(a), np.abs(b)))).sum())
+
+
+def run(test, N=(100, 100), **kw):
+    import armon_amd
+    opts = dict(test=test, N=N, maxcycle=1000, silent=5, return_data=True)
+    opts.update(kw)
+    params = armon_amd.ArmonParameters(**opts)
+    stats = armon_amd.armon(params)
+    host = stats.data.device_to_host()
+    return params, stats, host
+
+
+MODES = [pytest.param(False, id="staged"), pytest.param(True, id="fused")]
+
+
+@pytest.mark.parametrize("fused", MODES)
+@pytest.mark.parametrize("test", ["Sod", "Sod_y", "Sod_circ"])
+def test_reference_golden_sod_family(test, fused):
+    """ref test/gpu.jl:16-44 / test/convergence.jl:5-28 with the reference's own tolerance rule."""
+    g = load_golden(test)
+    params, stats, host = run(test, use_fused_sweep=fused)
+    assert stats.cycles == int(g["cycles"])
+    assert abs(stats.last_dt - float(g["dt"])) <= max(1e-13, 4 * EPS * float(g["dt"]))
+    grid = stats.data
+    for k in ("x", "y", "rho", "u", "v", "p"):
+        assert isapprox_count(grid.real_view(host[k]), g[k]) == 0, k
+
+
+@pytest.mark.parametrize("fused", MODES)
+@pytest.mark.parametrize("test", ["Bizarrium", "Sedov"])
+def test_reference_golden_unasserted_cases(test, fused):
+    g = load_golden(test)
+    params, stats, host = run(test, use_fused_sweep=fused)
+    assert stats.cycles == int(g["cycles"])
+    assert abs(stats.last_dt - float(g["dt"])) <= 1e-12 * float(g["dt"])
+    for k in ("rho", "u", "v", "p"):
+        a = stats.data.real_view(host[k])
+        assert np.abs(a - g[k]).max() <= 1e-12 * np.abs(g[k]).max(), k
+
+
+@pytest.mark.parametrize("fused", MODES)
+@pytest.mark.parametrize("test,N,opts", [
+    ("Sod", (100, 100), {}),
+    ("Sod_circ", (67, 41), {}),
+    ("Sedov", (50, 50), dict(maxcycle=40)),
+    ("Bizarrium", (64, 32), dict(maxcycle=30)),
+    ("Sod_circ", (48, 48), dict(scheme="Godunov", maxcycle=25)),
+    ("Sod_circ", (48, 48), dict(projection="euler", maxcycle=25)),
+    ("Sod_circ", (48, 48), dict(riemann_limiter="superbee", maxcycle=25)),
+    ("Sod_circ", (48, 48), dict(riemann_limiter="no_limiter", maxcycle=25)),
+    ("Sod_circ", (48, 40), dict(axis_splitting="Strang", maxcycle=15)),
+    ("Sod_circ", (48, 40), dict(axis_splitting="Godunov", maxcycle=15)),
+    ("Sod", (40, 8), dict(axis_splitting="X_only", maxcycle=15)),
+    ("Sod_y", (8, 40), dict(axis_splitting="Y_only", maxcycle=15)),
+    ("Sod_circ", (40, 40), dict(cst_dt=True, Dt=1e-3, maxcycle=15)),
+    ("Sod_circ", (40, 40), dict(scheme="Godunov", projection="euler", nghost=2, maxcycle=15)),
+    ("Sod_circ", (40, 40), dict(nghost=5, maxcycle=15)),
+])
+def test_bit_exact_against_oracle(oracle, test, N, opts, fused):
+    """Whole-solver parity: every real cell of ρ,u,v,E,p, the cycle count and dt are identical."""
+    params, stats, host = run(test, N=N, use_fused_sweep=fused, **opts)
+    orun, f = oracle.solve(test=test, N=N, **{"maxcycle": 1000, **opts})
+    assert stats.cycles == orun.cycles
+    assert stats.last_dt == orun.last_dt and stats.final_time == orun.final_time
+    g = opts.get("nghost", 4)
+    for k in ("rho", "u", "v", "E", "p"):
+        a = stats.data.real_view(host[k])
+        b = oracle.real_view(f[k], N[0], N[1], g)
+        assert np.array_equal(a, b), f"{k}: max abs diff {np.abs(a - b).max()}"
+
+
+@pytest.mark.parametrize("fused", MODES)
+@pytest.mark.parametrize("test", ["Sod", "Sod_y", "Sod_circ"])
+def test_conservation(test, fused):
+    """ref test/conservation.jl:1-16"""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, conservation_vars, init_test, time_loop
+    params = armon_amd.ArmonParameters(test=test, N=(100, 100), maxcycle=10000, silent=5, use_fused_sweep=fused)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    m0, e0 = conservation_vars(params, grid)
+    time_loop(params, grid)
+    m1, e1 = conservation_vars(params, grid)
+    assert abs(m1 - m0) <= 1e-12 and abs(e1 - e0) <= 1e-12
+
+
+@pytest.mark.parametrize("fused", MODES)
+@pytest.mark.parametrize("test,axis", [("Sod", 0), ("Sod_y", 1), ("Bizarrium", 0)])
+def test_axis_invariance(test, axis, fused):
+    """ref test/convergence.jl:31-64"""
+    params, stats, host = run(test, N=(40, 40), maxcycle=30, use_fused_sweep=fused)
+    for k in ("rho", "u", "v", "p", "E"):
+        a = stats.data.real_view(host[k])
+        ref = a[0:1, :] if axis == 0 else a[:, 0:1]
+        assert np.array_equal(a, np.broadcast_to(ref, a.shape)), k
+
+
+@pytest.mark.parametrize("fused", MODES)
+def test_ghost_garbage_does_not_propagate(fused):
+    """ref test/convergence.jl:67-102: 1e100 in every ghost cell of every array, same result."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, init_test, time_loop
+    N = (32, 24)
+    _, stats0, host0 = run("Sod_circ", N=N, maxcycle=12, use_fused_sweep=fused)
+    params = armon_amd.ArmonParameters(test="Sod_circ", N=N, maxcycle=12, silent=5, use_fused_sweep=fused)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    sx, sy = params.block_size.size
+    m = np.ones((sy, sx), dtype=bool)
+    m[G:G + N[1], G:G + N[0]] = False
+    for k in ("rho", "u", "v", "E", "p", "c", "g", "us", "ps", "work_1", "work_2", "work_3", "work_4"):
+        a = grid.data[k].to_host().reshape(sy, sx)
+        a[m] = 1e100
+        grid.data[k].copy_from_host(a.ravel())
+    if grid.alt:
+        for k in grid.alt:
+            grid.alt[k].copy_from_host(np.full(sx * sy, 1e100))
+    t, dt, cycles, _, _ = time_loop(params, grid)
+    assert cycles == stats0.cycles and dt == stats0.last_dt
+    host = grid.device_to_host()
+    for k in ("rho", "u", "v", "E", "p"):
+        assert np.array_equal(grid.real_view(host[k]), grid.real_view(host0[k])), k
+
+
+def test_invalid_time_step_is_reported():
+    """ref src/solver_state.jl:123-124 → SolverException(:time)"""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, init_test, time_loop
+    params = armon_amd.ArmonParameters(test="Sod", N=(16, 16), maxcycle=3, silent=5, use_fused_sweep=False)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    grid.data["E"].copy_from_host(np.full(params.block_size.n_cells, -1.0))   # e < 0 → NaN sound speed
+    with pytest.raises(armon_amd.SolverException) as e:
+        time_loop(params, grid)
+    assert e.value.category == "time"
