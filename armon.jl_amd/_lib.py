@@ -78,6 +78,8 @@ SIGNATURES = {
     "armon_hip_memset": (_ci, [_vp, _vp, _ci, C.c_size_t]),
     "armon_hip_timer_start": (_ci, [_vp]),
     "armon_hip_timer_stop": (_ci, [_vp, C.POINTER(_dbl)]),
+    "armon_hip_event_record": (_ci, [_vp, _ci]),
+    "armon_hip_event_elapsed_ms": (_ci, [_vp, _ci, _ci, C.POINTER(_dbl)]),
     "armon_hip_perfect_gas_EOS": (_ci, [_vp, Range, _dbl] + [_dp] * 7),
     "armon_hip_bizarrium_EOS": (_ci, [_vp, Range] + [_dp] * 7),
     "armon_hip_acoustic": (_ci, [_vp, Range, _i64] + [_dp] * 6),

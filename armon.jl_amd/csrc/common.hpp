@@ -21,6 +21,7 @@ struct armon_ctx {
     double* scalars = nullptr;       // [16] device doubles: results of reductions
     double* host_scalars = nullptr;  // [16] pinned host mirror
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t* ev_pool = nullptr;   // [ARMON_HIP_MAX_EVENTS], created on first use
     int n_cu = 256;
 };
 

@@ -104,6 +104,11 @@ int armon_hip_destroy(armon_ctx* ctx)
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->scalars) (void)hipFree(ctx->scalars);
     if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);
+    if (ctx->ev_pool) {
+        for (int i = 0; i < ARMON_HIP_MAX_EVENTS; i++)
+            if (ctx->ev_pool[i]) (void)hipEventDestroy(ctx->ev_pool[i]);
+        delete[] ctx->ev_pool;
+    }
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -197,6 +202,28 @@ int armon_hip_timer_stop(armon_ctx* ctx, double* elapsed_ms)
     ARMON_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
     float ms = 0.f;
     ARMON_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    *elapsed_ms = (double)ms;
+    return ARMON_OK;
+}
+
+int armon_hip_event_record(armon_ctx* ctx, int slot)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    ARMON_REQUIRE(slot >= 0 && slot < ARMON_HIP_MAX_EVENTS, "event slot %d out of range", slot);
+    if (!ctx->ev_pool) ctx->ev_pool = new hipEvent_t[ARMON_HIP_MAX_EVENTS]();
+    if (!ctx->ev_pool[slot]) ARMON_HIP_TRY(hipEventCreate(&ctx->ev_pool[slot]));
+    ARMON_HIP_TRY(hipEventRecord(ctx->ev_pool[slot], ctx->stream));
+    return ARMON_OK;
+}
+
+int armon_hip_event_elapsed_ms(armon_ctx* ctx, int a, int b, double* elapsed_ms)
+{
+    ARMON_REQUIRE(ctx && elapsed_ms, "NULL argument");
+    ARMON_REQUIRE(ctx->ev_pool && a >= 0 && b >= 0 && a < ARMON_HIP_MAX_EVENTS && b < ARMON_HIP_MAX_EVENTS &&
+                  ctx->ev_pool[a] && ctx->ev_pool[b], "events %d/%d were not recorded", a, b);
+    ARMON_HIP_TRY(hipEventSynchronize(ctx->ev_pool[b]));
+    float ms = 0.f;
+    ARMON_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_pool[a], ctx->ev_pool[b]));
     *elapsed_ms = (double)ms;
     return ARMON_OK;
 }

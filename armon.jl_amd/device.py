@@ -61,6 +61,14 @@ class HIPDevice:
         check(self._L.armon_hip_timer_stop(self.ctx, C.byref(ms)))
         return ms.value
 
+    def event_record(self, slot):
+        check(self._L.armon_hip_event_record(self.ctx, int(slot)))
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_double()
+        check(self._L.armon_hip_event_elapsed_ms(self.ctx, int(a), int(b), C.byref(ms)))
+        return ms.value
+
     # array constructors ------------------------------------------------------------------------
     def empty(self, n, dtype=np.float64):
         return DeviceArray(self, n, dtype)

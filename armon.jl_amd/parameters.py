@@ -165,6 +165,7 @@ class ArmonParameters:
     def _init_profiling(self, profiling=(), measure_time=True, time_async=True, log_blocks=False,
                         estimated_blk_log_size=0, **options):
         self.profiling = tuple(profiling)
+        self.kernel_callbacks = []      # ref register_kernel_callback, src/profiling.jl:30-68
         self.measure_time = measure_time
         self.time_async = time_async
         return options
@@ -272,3 +273,12 @@ def memory_required(N, nghost=4, data_type=np.float64, fused=True):
     the staged layout, +4 ping-pong arrays when the fused sweep is used."""
     n = (N[0] + 2 * nghost) * (N[1] + 2 * nghost)
     return n * np.dtype(data_type).itemsize * (16 + (4 if fused else 0))
+
+
+def proc_grid_for(world):
+    """Process grid used by the benchmarks: 1→(1,1), 2→(2,1), 4→(2,2), 8→(4,2) (BASELINE.json configs);
+    otherwise the most square px ≥ py factorisation."""
+    py = int(world ** 0.5)
+    while world % py:
+        py -= 1
+    return (world // py, py)

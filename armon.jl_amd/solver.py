@@ -154,6 +154,30 @@ def _L():
     return _lib.lib()
 
 
+class _KernelSection:
+    """Kernel profiling callbacks — ref ``kernel_start``/``kernel_end`` wrapped around every kernel launch
+    when profiling is enabled (ref src/generic_kernel.jl:869-876,892-908, src/profiling.jl:6-68).
+    ``params.kernel_callbacks`` = list of objects with ``start(name)`` / ``end(name)``."""
+    __slots__ = ("cbs", "name")
+
+    def __init__(self, params, name):
+        self.cbs = params.kernel_callbacks
+        self.name = name
+
+    def __enter__(self):
+        for cb in self.cbs:
+            cb.start(self.name)
+
+    def __exit__(self, *exc):
+        for cb in self.cbs:
+            cb.end(self.name)
+        return False
+
+
+def _k(params, name):
+    return _KernelSection(params, name)
+
+
 def _range(params, corners):
     return params.block_size.domain_range(*corners).to_c()
 
@@ -178,11 +202,13 @@ def update_EOS(params, grid, axis=Axis.X):
     r = _range(params, params.steps_ranges[axis].EOS)
     p = grid.ptr
     if params.test.eos == "bizarrium":
-        check(_L().armon_hip_bizarrium_EOS(params.device.ctx, r, p("rho"), p("u"), p("v"), p("E"),
-                                           p("p"), p("c"), p("g")))
+        with _k(params, "bizarrium_EOS"):
+            check(_L().armon_hip_bizarrium_EOS(params.device.ctx, r, p("rho"), p("u"), p("v"), p("E"),
+                                               p("p"), p("c"), p("g")))
     else:
-        check(_L().armon_hip_perfect_gas_EOS(params.device.ctx, r, params.test.gamma, p("rho"), p("E"),
-                                             p("u"), p("v"), p("p"), p("c"), p("g")))
+        with _k(params, "perfect_gas_EOS"):
+            check(_L().armon_hip_perfect_gas_EOS(params.device.ctx, r, params.test.gamma, p("rho"), p("E"),
+                                                 p("u"), p("v"), p("p"), p("c"), p("g")))
 
 
 def boundary_conditions(params, grid, axis, side):
@@ -216,10 +242,12 @@ def numerical_fluxes(params, grid, axis, dt, dx):
     p = grid.ptr
     ua = p("u") if axis == Axis.X else p("v")
     if params.riemann_scheme == "GAD":
-        check(_L().armon_hip_acoustic_GAD(params.device.ctx, r, s, dt, dx, p("us"), p("ps"), p("rho"), ua,
-                                          p("p"), p("c"), LIMITERS[params.riemann_limiter]))
+        with _k(params, "acoustic_GAD"):
+            check(_L().armon_hip_acoustic_GAD(params.device.ctx, r, s, dt, dx, p("us"), p("ps"), p("rho"), ua,
+                                              p("p"), p("c"), LIMITERS[params.riemann_limiter]))
     else:
-        check(_L().armon_hip_acoustic(params.device.ctx, r, s, p("us"), p("ps"), p("rho"), ua, p("p"), p("c")))
+        with _k(params, "acoustic"):
+            check(_L().armon_hip_acoustic(params.device.ctx, r, s, p("us"), p("ps"), p("rho"), ua, p("p"), p("c")))
 
 
 def cell_update(params, grid, axis, dt, dx):
@@ -228,7 +256,8 @@ def cell_update(params, grid, axis, dt, dx):
     s = params.block_size.stride_along(axis)
     p = grid.ptr
     ua = p("u") if axis == Axis.X else p("v")
-    check(_L().armon_hip_cell_update(params.device.ctx, r, s, dx, dt, p("us"), p("ps"), p("rho"), ua, p("E")))
+    with _k(params, "cell_update"):
+        check(_L().armon_hip_cell_update(params.device.ctx, r, s, dx, dt, p("us"), p("ps"), p("rho"), ua, p("E")))
 
 
 def projection_remap(params, grid, axis, dt, dx):
@@ -238,14 +267,17 @@ def projection_remap(params, grid, axis, dt, dx):
     ra = _range(params, params.steps_ranges[axis].advection)
     w = (p("work_1"), p("work_2"), p("work_3"), p("work_4"))
     if params.projection_scheme == "euler_2nd":
-        check(_L().armon_hip_advection_second_order(params.device.ctx, ra, s, dx, dt, p("us"), p("rho"),
-                                                    p("u"), p("v"), p("E"), *w))
+        with _k(params, "advection_second_order"):
+            check(_L().armon_hip_advection_second_order(params.device.ctx, ra, s, dx, dt, p("us"), p("rho"),
+                                                        p("u"), p("v"), p("E"), *w))
     else:
-        check(_L().armon_hip_advection_first_order(params.device.ctx, ra, s, dt, p("us"), p("rho"),
-                                                   p("u"), p("v"), p("E"), *w))
+        with _k(params, "advection_first_order"):
+            check(_L().armon_hip_advection_first_order(params.device.ctx, ra, s, dt, p("us"), p("rho"),
+                                                       p("u"), p("v"), p("E"), *w))
     rp = _range(params, params.steps_ranges[axis].projection)
-    check(_L().armon_hip_euler_projection(params.device.ctx, rp, s, dx, dt, p("us"), p("rho"), p("u"),
-                                          p("v"), p("E"), *w))
+    with _k(params, "euler_projection"):
+        check(_L().armon_hip_euler_projection(params.device.ctx, rp, s, dx, dt, p("us"), p("rho"), p("u"),
+                                              p("v"), p("E"), *w))
 
 
 def local_time_step(params, grid):
@@ -255,7 +287,8 @@ def local_time_step(params, grid):
     dy = params.domain_size[1] / params.global_grid[1]
     out = C.c_double()
     p = grid.ptr
-    check(_L().armon_hip_dtCFL(params.device.ctx, r, dx, dy, p("u"), p("v"), p("c"), C.byref(out)))
+    with _k(params, "dtCFL"):
+        check(_L().armon_hip_dtCFL(params.device.ctx, r, dx, dy, p("u"), p("v"), p("c"), C.byref(out)))
     return out.value
 
 
@@ -304,7 +337,8 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False):
     d.rho_out, d.u_out, d.v_out, d.E_out = (grid.alt[f].ptr for f in STATE_VARS)
     d.p_out = grid.data["p"].ptr if emit_p else None
     d.c_out = grid.data["c"].ptr if emit_c else None
-    check(_L().armon_hip_sweep(params.device.ctx, C.byref(d)))
+    with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
+        check(_L().armon_hip_sweep(params.device.ctx, C.byref(d)))
     grid.swap_state()
 
 

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Benchmark of the direction-split sweep hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one solver cycle of the reference's time loop (ref src/solver.jl:288-320): the dt/CFL
+reduction + one X sweep + one Y sweep over the whole grid. Inputs are the reference's own deterministic
+initial conditions (init_test) already resident in HBM. Prints ONE JSON line on rank 0:
+
+ value      = Mcells/s per sweep = cells(all ranks) · 2 sweeps · K / time / 1e6       
+ roofline   = dominant kernel (the fused sweep, or euler_projection in --staged mode) timed live with
+              HIP events on the kernel's stream; achieved = algorithmic B/cell · cells / mean duration
+ cpu_baseline = the CPU oracle ("port": OpenMP restatement of the reference's 5-pass CPU path) timed on
+              this host's cores on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic fp64 bytes per cell
+B_PER_CELL = {"sweep_x": 64, "sweep_y": 64, "euler_projection": 112, "advection_second_order": 72,
+              "advection_first_order": 72, "cell_update": 64, "acoustic_GAD": 48, "acoustic": 48,
+              "perfect_gas_EOS": 56, "bizarrium_EOS": 56, "dtCFL": 24}
+
+
+class EventTimer:
+    """kernel_start/kernel_end callback recording HIP events around chosen kernels (no host sync)."""
+
+    def __init__(self, device, names, max_pairs=500):
+        self.device, self.names, self.max_pairs = device, set(names), max_pairs
+        self.pairs = []          # (name, slot_a, slot_b)
+        self.enabled = False
+
+    def start(self, name):
+        if self.enabled and name in self.names and len(self.pairs) < self.max_pairs:
+            self.device.event_record(2 * len(self.pairs))
+
+    def end(self, name):
+        if self.enabled and name in self.names and len(self.pairs) < self.max_pairs:
+            n = len(self.pairs)
+            self.device.event_record(2 * n + 1)
+            self.pairs.append((name, 2 * n, 2 * n + 1))
+
+    def durations_ms(self):
+        out = {}
+        for name, a, b in self.pairs:
+            out.setdefault(name, []).append(self.device.event_elapsed_ms(a, b))
+        return out
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(cores, 64)
+
+
+def cpu_baseline(test, scheme, target_seconds=12.0):
+    """Time the CPU oracle (kind "port") on the host cores: bounded sample of the same workload."""
+    from oracle import oracle as O
+    cores = usable_cores()
+    n = 4096 if cores >= 8 else 2048
+    fields = O.alloc_fields(n, n, 4)
+    kw = dict(test=test, N=(n, n), scheme=scheme, threads=cores, native=True, fields=fields, maxtime=1e9)
+    O.solve(maxcycle=1, **kw)                                   # warm-up: page-touch + init
+    run, _ = O.solve(maxcycle=2, **kw)
+    per_cycle = run.solve_seconds / 2
+    cycles = int(max(2, min(40, target_seconds / max(per_cycle, 1e-6))))
+    run, _ = O.solve(maxcycle=cycles, **kw)
+    value = n * n * 2 * run.cycles / run.solve_seconds / 1e6
+    return {"value": round(value, 2), "unit": "Mcells/s per sweep", "cores": cores, "kind": "port",
+            "sample": f"{test} {n}x{n} fp64 {scheme}+minmod+euler_2nd, {run.cycles} cycles "
+                      f"({run.solve_seconds:.1f} s), oracle/armon_oracle.c -O2 -march=native OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=16384, help="cells per axis PER GPU (weak scaling)")
+    ap.add_argument("--test", default="Sod")
+    ap.add_argument("--scheme", default="GAD")
+    ap.add_argument("--staged", action="store_true", help="5 staged kernels per sweep instead of the fused one")
+    ap.add_argument("--fast", action="store_true", help="tuned arithmetic (shared reciprocals, FMA)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import armon_amd
+    from armon_amd.parameters import proc_grid_for
+    from armon_amd.solver import BlockGrid, init_test, solver_cycle
+
+    P = proc_grid_for(world)                                  # (px, py), e.g. 8 → (4, 2)
+    N_global = (args.n * P[0], args.n * P[1])                 # weak scaling: n×n cells per GPU
+    params = armon_amd.ArmonParameters(
+        test=args.test, N=N_global, scheme=args.scheme, riemann_limiter="minmod", projection="euler_2nd",
+        axis_splitting="Sequential", nghost=4, maxtime=1e9, maxcycle=10 ** 9, silent=5,
+        use_MPI=world > 1, P=P, device_id=local_rank,
+        use_fused_sweep=not args.staged, exact_arithmetic=not args.fast)
+    grid = BlockGrid(params)
+    if world > 1:
+        from armon_amd.halo_exchange import setup
+        setup(params, grid)
+    init_test(params, grid)
+    gdt = grid.global_dt
+    gdt.reset()
+
+    dominant = ("sweep_x", "sweep_y") if not args.staged else ("euler_projection",)
+    timer = EventTimer(params.device, dominant)
+    params.kernel_callbacks.append(timer)
+
+    def barrier():
+        params.wait()
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver_cycle(params, grid)
+        gdt.next_cycle()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver_cycle(params, grid)
+        gdt.next_cycle()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cells_local = params.N[0] * params.N[1]
+    cells_total = N_global[0] * N_global[1]
+    sweeps = 2 * args.steps
+    value = cells_total * sweeps / elapsed / 1e6
+
+    durs = timer.durations_ms()
+    all_ms = [d for v in durs.values() for d in v]
+    mean_ms = sum(all_ms) / max(len(all_ms), 1)
+    bpc = B_PER_CELL[dominant[0]]
+    achieved = bpc * cells_local / (mean_ms * 1e-3) / 1e9 if all_ms else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": "+".join(dominant), "bytes_per_cell": bpc, "launches_timed": len(all_ms),
+                "mean_launch_ms": round(mean_ms, 4),
+                "per_kernel_ms": {k: round(sum(v) / len(v), 4) for k, v in durs.items()}}
+
+    out = {
+        "metric": "Mcells/sec per sweep (fp64)", "value": round(value, 1), "unit": "Mcells/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.test} {N_global[0]}x{N_global[1]} fp64, {args.scheme}+minmod+euler_2nd, "
+                               f"Sequential X,Y splitting, nghost 4, {args.n}x{args.n} cells per GPU",
+                   "path": "staged (5 kernels/sweep)" if args.staged else "fused sweep",
+                   "arithmetic": "fast" if args.fast else "exact (IEEE div/sqrt, no contraction)",
+                   "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local},
+        "hbm_GBps_algorithmic_whole_job": round(64 * cells_total * sweeps / elapsed / 1e9, 1),
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args.test, args.scheme)
+        except Exception as e:   # the baseline is a reported extra: never lose the GPU line over it
+            out["cpu_baseline"] = {"value": None, "unit": "Mcells/s per sweep", "cores": 0,
+                                   "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,7 +97,12 @@ ARMON_API int armon_hip_free(armon_ctx* ctx, void* ptr);
 ARMON_API int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind); /* async */
 ARMON_API int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes);             /* async */
 
-/* stream timers for benchmarks (hipEvent pairs on the context's stream) */
+/* stream timers for benchmarks (hipEvents on the context's stream).
+ * event_record/event_elapsed: a pool of ARMON_HIP_MAX_EVENTS reusable events, recorded without any
+ * host synchronisation; event_elapsed_ms synchronises on event `b` and returns t(b) - t(a). */
+#define ARMON_HIP_MAX_EVENTS 1024
+ARMON_API int armon_hip_event_record(armon_ctx* ctx, int slot);
+ARMON_API int armon_hip_event_elapsed_ms(armon_ctx* ctx, int a, int b, double* elapsed_ms);
 ARMON_API int armon_hip_timer_start(armon_ctx* ctx);
 ARMON_API int armon_hip_timer_stop(armon_ctx* ctx, double* elapsed_ms);        /* synchronises on the stop event */
 
