@@ -1,8 +1,290 @@
-// fused_sweep.hip — placeholder until the fused kernels land (next commit).
+// fused_sweep.hip — armon_hip_sweep: one directional sweep of solver_cycle (ref src/solver.jl:300-316)
+// as ONE kernel launch: EOS → boundary mirror → fluxes → cell update → advection → projection, reading
+// ρ,u,v,E once and writing them once (64 B per cell instead of the 352 B of the five staged passes).
+//
+// Both kernels run the register pipeline of sweep_pipeline.hpp; they differ only in how a lane gets the
+// cells it marches over:
+//  * Y sweep: lane ↔ column. Rows are x-contiguous, so every step of the march is one fully coalesced
+//    row segment per wave; no LDS at all. A workgroup owns 256 columns × one run of rows.
+//  * X sweep: the march runs along the contiguous axis, so lane ↔ row and the wave transposes through
+//    LDS: a 64-row × CH-column tile is loaded with coalesced row segments, each lane walks its row in
+//    LDS (odd row pitch → conflict-free column reads), writes the results back in place, and the tile
+//    is stored with coalesced row segments again. One wave per workgroup, so the barriers are free.
+// Redundant work is confined to the LAG (≤4) cells at both ends of a run.
 #include "common.hpp"
+#include "sweep_pipeline.hpp"
+
 using namespace armon;
+
+namespace {
+
+struct sweep_args {
+    int64_t nx, ny, row_len;       // real cells and array pitch (nx + 2g)
+    int32_t g;                     // ghost layers
+    int32_t bc_low, bc_high;       // mirror BC applied in-kernel on that side of the sweep axis
+    int32_t emit;                  // bit 0: write p_out, bit 1: write c_out
+    int64_t seg;                   // cells per run along the sweep axis
+    double dt, dx, gamma;
+    double fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
+    const double *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
+    double *rho_out, *ua_out, *ut_out, *E_out;
+    double *p_out, *c_out;
+};
+
+// Source index and velocity factors of cell `j` (0-based real coordinate along the sweep axis, may be
+// a ghost): physical boundaries mirror the inside (ref src/halo_exchange.jl:2-29), process boundaries
+// read the ghost cells filled by the halo exchange.
+__device__ __forceinline__ int64_t bc_source(const sweep_args& a, int64_t n, int64_t j, double& fa, double& ft)
+{
+    fa = 1.;
+    ft = 1.;
+    if (j < 0 && a.bc_low) {
+        fa = a.fa_low;
+        ft = a.ft_low;
+        return -1 - j;
+    }
+    if (j >= n && a.bc_high) {
+        fa = a.fa_high;
+        ft = a.ft_high;
+        return 2 * n - 1 - j;
+    }
+    return j;
+}
+
+// ---- Y sweep ---------------------------------------------------------------------------------------
+constexpr int kYBlock = 256;
+
+template <class PIPE>
+__global__ void __launch_bounds__(kYBlock)
+k_sweep_y(sweep_args a)
+{
+    constexpr int LAG = PIPE::LAG;
+    const int64_t x = (int64_t)blockIdx.x * kYBlock + threadIdx.x;
+    if (x >= a.nx) return;
+    const int64_t o0 = (int64_t)blockIdx.y * a.seg;
+    const int64_t o1 = (o0 + a.seg < a.ny) ? o0 + a.seg : a.ny;
+    const int64_t col = x + a.g;
+
+    PIPE pipe(a.dt, a.dx, a.gamma);
+
+    double fa, ft;
+    int64_t src = bc_source(a, a.ny, o0 - LAG, fa, ft);
+    int64_t idx = (src + a.g) * a.row_len + col;
+    double n_rho = a.rho_in[idx], n_ua = a.ua_in[idx] * fa, n_ut = a.ut_in[idx] * ft, n_E = a.E_in[idx];
+
+    for (int64_t j = o0 - LAG; j < o1 + LAG; ++j) {
+        const double rho = n_rho, ua = n_ua, ut = n_ut, E = n_E;
+        if (j + 1 < o1 + LAG) {   // software prefetch of the next row while this one is computed
+            src = bc_source(a, a.ny, j + 1, fa, ft);
+            idx = (src + a.g) * a.row_len + col;
+            n_rho = a.rho_in[idx];
+            n_ua = a.ua_in[idx] * fa;
+            n_ut = a.ut_in[idx] * ft;
+            n_E = a.E_in[idx];
+        }
+        double p, c;
+        const fused::Out4 out = pipe.template push<true>(rho, ua, ut, E, p, c);
+        if (a.emit && j >= o0 && j < o1) {
+            const int64_t ij = (j + a.g) * a.row_len + col;
+            if (a.emit & 1) a.p_out[ij] = p;
+            if (a.emit & 2) a.c_out[ij] = c;
+        }
+        const int64_t o = j - LAG;
+        if (o >= o0) {
+            const int64_t io = (o + a.g) * a.row_len + col;
+            a.rho_out[io] = out.rho;
+            a.ua_out[io] = out.ua;
+            a.ut_out[io] = out.ut;
+            a.E_out[io] = out.E;
+        }
+    }
+}
+
+// ---- X sweep ---------------------------------------------------------------------------------------
+constexpr int kXRows = 64;      // one wave: lane ↔ row
+
+template <class PIPE, int CH>
+__global__ void __launch_bounds__(kXRows, 2)
+k_sweep_x(sweep_args a)
+{
+    constexpr int LAG = PIPE::LAG;
+    constexpr int PITCH = CH + 1;                 // odd pitch in doubles: conflict-free column walks
+    constexpr int RPI = kXRows / CH;              // rows covered by one wave-wide row-segment access
+    extern __shared__ double tile[];              // [planes][64][PITCH], planes = 4 (+2 when emitting p, c)
+
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * kXRows;
+    const int64_t o0 = (int64_t)blockIdx.x * a.seg;
+    const int64_t o1 = (o0 + a.seg < a.nx) ? o0 + a.seg : a.nx;
+    const int64_t j_end = o1 + LAG;
+    const bool row_ok = (r0 + lane) < a.ny;
+    const bool emit = a.emit != 0;
+
+    const int sub_row = lane / CH, sub_col = lane % CH;   // row-segment phase: lane → (row in group, column)
+    auto T = [&](int plane, int r, int t) -> double& { return tile[(plane * kXRows + r) * PITCH + t]; };
+
+    PIPE pipe(a.dt, a.dx, a.gamma);
+
+    for (int64_t jb = o0 - LAG; jb < j_end; jb += CH) {
+        // -- load phase: 64 rows × CH columns, 8 B per lane, CH*8 B contiguous per row
+        {
+            const int64_t j = jb + sub_col;
+            double fa, ft;
+            const int64_t src = bc_source(a, a.nx, j, fa, ft);
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int r = k * RPI + sub_row;
+                const int64_t row = r0 + r;
+                if (row < a.ny && j < j_end) {
+                    const int64_t idx = (row + a.g) * a.row_len + (src + a.g);
+                    T(0, r, sub_col) = a.rho_in[idx];
+                    T(1, r, sub_col) = a.ua_in[idx] * fa;
+                    T(2, r, sub_col) = a.ut_in[idx] * ft;
+                    T(3, r, sub_col) = a.E_in[idx];
+                }
+            }
+        }
+        __syncthreads();
+        // -- march: lane walks its own row through the tile, results overwrite the consumed slots
+        if (row_ok) {
+#pragma unroll
+            for (int t = 0; t < CH; t++) {
+                const int64_t j = jb + t;
+                if (j < j_end) {
+                    double p, c;
+                    const fused::Out4 out = pipe.template push<false>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c);
+                    T(0, lane, t) = out.rho;
+                    T(1, lane, t) = out.ua;
+                    T(2, lane, t) = out.ut;
+                    T(3, lane, t) = out.E;
+                    if (emit) {
+                        T(4, lane, t) = p;
+                        T(5, lane, t) = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // -- store phase: slot t holds the new state of column jb + t - LAG (and p, c of column jb + t)
+        {
+            const int64_t j = jb + sub_col;
+            const int64_t o = j - LAG;
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int r = k * RPI + sub_row;
+                const int64_t row = r0 + r;
+                if (row < a.ny && j < j_end) {
+                    if (o >= o0) {
+                        const int64_t io = (row + a.g) * a.row_len + (o + a.g);
+                        a.rho_out[io] = T(0, r, sub_col);
+                        a.ua_out[io] = T(1, r, sub_col);
+                        a.ut_out[io] = T(2, r, sub_col);
+                        a.E_out[io] = T(3, r, sub_col);
+                    }
+                    if (emit && j >= o0 && j < o1) {
+                        const int64_t ij = (row + a.g) * a.row_len + (j + a.g);
+                        if (a.emit & 1) a.p_out[ij] = T(4, r, sub_col);
+                        if (a.emit & 2) a.c_out[ij] = T(5, r, sub_col);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int kXChunk = 8;
+
+template <class PIPE>
+int launch(armon_ctx* ctx, const sweep_args& a, int axis)
+{
+    if (axis == ARMON_AXIS_Y) {
+        dim3 grid((unsigned)((a.nx + kYBlock - 1) / kYBlock), (unsigned)((a.ny + a.seg - 1) / a.seg));
+        hipLaunchKernelGGL(k_sweep_y<PIPE>, grid, dim3(kYBlock), 0, ctx->stream, a);
+        return check_launch("sweep_y");
+    }
+    dim3 grid((unsigned)((a.nx + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
+    const size_t lds = (size_t)(a.emit ? 6 : 4) * kXRows * (kXChunk + 1) * sizeof(double);
+    hipLaunchKernelGGL((k_sweep_x<PIPE, kXChunk>), grid, dim3(kXRows), lds, ctx->stream, a);
+    return check_launch("sweep_x");
+}
+
+template <int SCHEME, int LIM, int PROJ>
+int dispatch_eos(armon_ctx* ctx, const sweep_args& a, int axis, int eos)
+{
+    if (eos == ARMON_EOS_BIZARRIUM)
+        return launch<fused::Pipe<SCHEME, LIM, PROJ, ARMON_EOS_BIZARRIUM, true>>(ctx, a, axis);
+    return launch<fused::Pipe<SCHEME, LIM, PROJ, ARMON_EOS_PERFECT_GAS, true>>(ctx, a, axis);
+}
+
+template <int SCHEME, int LIM>
+int dispatch_proj(armon_ctx* ctx, const sweep_args& a, int axis, int eos, int proj)
+{
+    if (proj == ARMON_PROJECTION_EULER_2ND)
+        return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER_2ND>(ctx, a, axis, eos);
+    return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER>(ctx, a, axis, eos);
+}
+
+}  // namespace
+
 extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
 {
     ARMON_REQUIRE(ctx && d, "NULL argument");
-    ARMON_REQUIRE(false, "fused sweep not built yet");
+    ARMON_REQUIRE(d->axis == ARMON_AXIS_X || d->axis == ARMON_AXIS_Y, "invalid axis %d", d->axis);
+    ARMON_REQUIRE(d->scheme == ARMON_SCHEME_GODUNOV || d->scheme == ARMON_SCHEME_GAD, "unknown scheme %d", d->scheme);
+    ARMON_REQUIRE(d->projection == ARMON_PROJECTION_EULER || d->projection == ARMON_PROJECTION_EULER_2ND,
+                  "unknown projection %d", d->projection);
+    ARMON_REQUIRE(d->eos == ARMON_EOS_PERFECT_GAS || d->eos == ARMON_EOS_BIZARRIUM, "unknown EOS %d", d->eos);
+    ARMON_REQUIRE(d->scheme != ARMON_SCHEME_GAD || (d->limiter >= ARMON_LIMITER_NONE && d->limiter <= ARMON_LIMITER_SUPERBEE),
+                  "unknown limiter tag %d", d->limiter);
+    ARMON_REQUIRE(d->nx > 0 && d->ny > 0, "empty block %lld x %lld", (long long)d->nx, (long long)d->ny);
+    const int lag = (d->scheme == ARMON_SCHEME_GAD ? 1 : 0) + (d->projection == ARMON_PROJECTION_EULER_2ND ? 1 : 0) + 2;
+    ARMON_REQUIRE(d->nghost >= lag, "nghost = %d but this scheme/projection reads %d cells past the block", d->nghost, lag);
+    const int64_t n_axis = d->axis == ARMON_AXIS_X ? d->nx : d->ny;
+    ARMON_REQUIRE(!(d->bc_low || d->bc_high) || n_axis >= lag,
+                  "mirror boundary needs at least %d cells along the sweep axis", lag);
+    ARMON_REQUIRE(d->rho_in && d->u_in && d->v_in && d->E_in && d->rho_out && d->u_out && d->v_out && d->E_out,
+                  "NULL state array");
+    ARMON_REQUIRE(d->rho_in != d->rho_out && d->u_in != d->u_out && d->v_in != d->v_out && d->E_in != d->E_out,
+                  "in and out arrays must not alias (ping-pong)");
+    ARMON_REQUIRE(d->exact == 1, "only exact arithmetic is built so far");
+
+    sweep_args a;
+    a.nx = d->nx;
+    a.ny = d->ny;
+    a.row_len = d->nx + 2 * (int64_t)d->nghost;
+    a.g = d->nghost;
+    a.bc_low = d->bc_low;
+    a.bc_high = d->bc_high;
+    a.emit = (d->p_out ? 1 : 0) | (d->c_out ? 2 : 0);
+    a.dt = d->dt;
+    a.dx = d->dx;
+    a.gamma = d->gamma;
+    const bool X = d->axis == ARMON_AXIS_X;
+    a.fa_low = X ? d->u_factor_low : d->v_factor_low;
+    a.ft_low = X ? d->v_factor_low : d->u_factor_low;
+    a.fa_high = X ? d->u_factor_high : d->v_factor_high;
+    a.ft_high = X ? d->v_factor_high : d->u_factor_high;
+    a.rho_in = d->rho_in;
+    a.ua_in = X ? d->u_in : d->v_in;
+    a.ut_in = X ? d->v_in : d->u_in;
+    a.E_in = d->E_in;
+    a.rho_out = d->rho_out;
+    a.ua_out = X ? d->u_out : d->v_out;
+    a.ut_out = X ? d->v_out : d->u_out;
+    a.E_out = d->E_out;
+    a.p_out = d->p_out;
+    a.c_out = d->c_out;
+    a.seg = X ? 512 : 128;
+
+    if (d->scheme == ARMON_SCHEME_GODUNOV)
+        return dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection);
+    switch (d->limiter) {
+    case ARMON_LIMITER_MINMOD:
+        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD>(ctx, a, d->axis, d->eos, d->projection);
+    case ARMON_LIMITER_SUPERBEE:
+        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_SUPERBEE>(ctx, a, d->axis, d->eos, d->projection);
+    default:
+        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection);
+    }
 }
