@@ -14,6 +14,9 @@
 #include "common.hpp"
 #include "sweep_pipeline.hpp"
 
+#include <type_traits>
+#include <utility>
+
 using namespace armon;
 
 namespace {
@@ -51,6 +54,12 @@ __device__ __forceinline__ int64_t bc_source(const sweep_args& a, int64_t n, int
     return j;
 }
 
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
 // ---- Y sweep ---------------------------------------------------------------------------------------
 constexpr int kYBlock = 256;
 
@@ -67,36 +76,47 @@ k_sweep_y(sweep_args a)
 
     PIPE pipe(a.dt, a.dx, a.gamma);
 
-    double fa, ft;
-    int64_t src = bc_source(a, a.ny, o0 - LAG, fa, ft);
-    int64_t idx = (src + a.g) * a.row_len + col;
-    double n_rho = a.rho_in[idx], n_ua = a.ua_in[idx] * fa, n_ut = a.ut_in[idx] * ft, n_E = a.E_in[idx];
-
-    for (int64_t j = o0 - LAG; j < o1 + LAG; ++j) {
+    const int64_t j_begin = o0 - LAG, j_end = o1 + LAG;
+    double n_rho, n_ua, n_ut, n_E;
+    // Loads one row of this lane's column (clamped to the run so that padding steps stay in bounds).
+    auto load = [&](int64_t j) {
+        double fa, ft;
+        const int64_t jc = j < j_end ? j : j_end - 1;
+        const int64_t src = bc_source(a, a.ny, jc, fa, ft);
+        const int64_t idx = (src + a.g) * a.row_len + col;
+        n_rho = a.rho_in[idx];
+        n_ua = a.ua_in[idx] * fa;
+        n_ut = a.ut_in[idx] * ft;
+        n_E = a.E_in[idx];
+    };
+    auto step = [&](auto ph, int64_t j) {
+        constexpr int PH = decltype(ph)::value;
         const double rho = n_rho, ua = n_ua, ut = n_ut, E = n_E;
-        if (j + 1 < o1 + LAG) {   // software prefetch of the next row while this one is computed
-            src = bc_source(a, a.ny, j + 1, fa, ft);
-            idx = (src + a.g) * a.row_len + col;
-            n_rho = a.rho_in[idx];
-            n_ua = a.ua_in[idx] * fa;
-            n_ut = a.ut_in[idx] * ft;
-            n_E = a.E_in[idx];
-        }
+        load(j + 1);   // software prefetch of the next row while this one is computed
         double p, c;
-        const fused::Out4 out = pipe.template push<true>(rho, ua, ut, E, p, c);
+        const fused::Out4 out = pipe.template push<true, PH>(rho, ua, ut, E, p, c);
         if (a.emit && j >= o0 && j < o1) {
             const int64_t ij = (j + a.g) * a.row_len + col;
             if (a.emit & 1) a.p_out[ij] = p;
             if (a.emit & 2) a.c_out[ij] = c;
         }
         const int64_t o = j - LAG;
-        if (o >= o0) {
+        if (o >= o0 && o < o1) {
             const int64_t io = (o + a.g) * a.row_len + col;
             a.rho_out[io] = out.rho;
             a.ua_out[io] = out.ua;
             a.ut_out[io] = out.ut;
             a.E_out[io] = out.E;
         }
+    };
+
+    load(j_begin);
+    // The march is unrolled by the 4 phases of the pipeline's history rings.
+    for (int64_t j = j_begin; j < j_end; j += 4) {
+        step(std::integral_constant<int, 0>{}, j);
+        step(std::integral_constant<int, 1>{}, j + 1);
+        step(std::integral_constant<int, 2>{}, j + 2);
+        step(std::integral_constant<int, 3>{}, j + 3);
     }
 }
 
@@ -147,12 +167,12 @@ k_sweep_x(sweep_args a)
         __syncthreads();
         // -- march: lane walks its own row through the tile, results overwrite the consumed slots
         if (row_ok) {
-#pragma unroll
-            for (int t = 0; t < CH; t++) {
+            static_for(std::make_integer_sequence<int, CH>{}, [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
                 const int64_t j = jb + t;
                 if (j < j_end) {
                     double p, c;
-                    const fused::Out4 out = pipe.template push<false>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c);
+                    const fused::Out4 out = pipe.template push<false, (t & 3)>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c);
                     T(0, lane, t) = out.rho;
                     T(1, lane, t) = out.ua;
                     T(2, lane, t) = out.ut;
@@ -162,7 +182,7 @@ k_sweep_x(sweep_args a)
                         T(5, lane, t) = c;
                     }
                 }
-            }
+            });
         }
         __syncthreads();
         // -- store phase: slot t holds the new state of column jb + t - LAG (and p, c of column jb + t)
@@ -209,20 +229,27 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis)
     return check_launch("sweep_x");
 }
 
+template <int SCHEME, int LIM, int PROJ, int EOS>
+int dispatch_exact(armon_ctx* ctx, const sweep_args& a, int axis, bool exact)
+{
+    if (exact) return launch<fused::Pipe<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis);
+    return launch<fused::PipeFast<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis);
+}
+
 template <int SCHEME, int LIM, int PROJ>
-int dispatch_eos(armon_ctx* ctx, const sweep_args& a, int axis, int eos)
+int dispatch_eos(armon_ctx* ctx, const sweep_args& a, int axis, int eos, bool exact)
 {
     if (eos == ARMON_EOS_BIZARRIUM)
-        return launch<fused::Pipe<SCHEME, LIM, PROJ, ARMON_EOS_BIZARRIUM, true>>(ctx, a, axis);
-    return launch<fused::Pipe<SCHEME, LIM, PROJ, ARMON_EOS_PERFECT_GAS, true>>(ctx, a, axis);
+        return dispatch_exact<SCHEME, LIM, PROJ, ARMON_EOS_BIZARRIUM>(ctx, a, axis, exact);
+    return dispatch_exact<SCHEME, LIM, PROJ, ARMON_EOS_PERFECT_GAS>(ctx, a, axis, exact);
 }
 
 template <int SCHEME, int LIM>
-int dispatch_proj(armon_ctx* ctx, const sweep_args& a, int axis, int eos, int proj)
+int dispatch_proj(armon_ctx* ctx, const sweep_args& a, int axis, int eos, int proj, bool exact)
 {
     if (proj == ARMON_PROJECTION_EULER_2ND)
-        return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER_2ND>(ctx, a, axis, eos);
-    return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER>(ctx, a, axis, eos);
+        return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER_2ND>(ctx, a, axis, eos, exact);
+    return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER>(ctx, a, axis, eos, exact);
 }
 
 }  // namespace
@@ -247,7 +274,7 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
                   "NULL state array");
     ARMON_REQUIRE(d->rho_in != d->rho_out && d->u_in != d->u_out && d->v_in != d->v_out && d->E_in != d->E_out,
                   "in and out arrays must not alias (ping-pong)");
-    ARMON_REQUIRE(d->exact == 1, "only exact arithmetic is built so far");
+    const bool exact = d->exact != 0;
 
     sweep_args a;
     a.nx = d->nx;
@@ -278,13 +305,13 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     a.seg = X ? 512 : 128;
 
     if (d->scheme == ARMON_SCHEME_GODUNOV)
-        return dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection);
+        return dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact);
     switch (d->limiter) {
     case ARMON_LIMITER_MINMOD:
-        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD>(ctx, a, d->axis, d->eos, d->projection);
+        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD>(ctx, a, d->axis, d->eos, d->projection, exact);
     case ARMON_LIMITER_SUPERBEE:
-        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_SUPERBEE>(ctx, a, d->axis, d->eos, d->projection);
+        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_SUPERBEE>(ctx, a, d->axis, d->eos, d->projection, exact);
     default:
-        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection);
+        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact);
     }
 }

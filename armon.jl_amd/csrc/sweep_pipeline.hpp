@@ -4,14 +4,21 @@
 // reference passes between its five per-sweep kernels through memory (p, c, uˢ, pˢ, work_1..4 —
 // ref src/solver.jl:300-316): EOS → first-order interface solve → GAD limited flux → Lagrangian cell
 // update → advection (with minmod slopes) → Euler projection. Each step consumes the state of cell j
-// and emits the post-sweep state of cell j - LAG, LAG = stencil(scheme) + stencil(projection) - ... =
-// 2..4, i.e. exactly the dependency cone i-LAG..i+LAG of the reference.
-// Every interface solve, flux, update, slope and advection is computed ONCE (the staged GAD kernel
-// solves each interface three times, ref src/riemann_schemes.jl:63-80).
+// and emits the post-sweep state of cell j - LAG, LAG = 2 + [GAD] + [euler_2nd] = 2..4, i.e. exactly
+// the dependency cone i-LAG..i+LAG of the reference. Every interface solve, flux,
+// update, slope and advection is computed ONCE (the staged GAD kernel solves each interface three
+// times, ref src/riemann_schemes.jl:63-80).
 //
-// Arithmetic: the EXACT instantiation evaluates the same IEEE operations in the same order as the
-// staged kernels / the reference formulas, so results are bit-identical; the tuned instantiation shares
-// reciprocals and uses FMAs (see fast:: below).
+// History lives in rings of 4 (2 for slopes / advection fluxes) indexed by the step's phase
+// PH = step mod 4, a template parameter: callers unroll the march by 4, every ring index is a
+// compile-time constant and no register is ever moved to "shift" the history.
+//
+// Two arithmetic flavours with the same interface:
+//  * Pipe      — EXACT: the same IEEE operations in the same order as the staged kernels and the
+//                reference formulas (bit-identical results; needs -ffp-contract=off).
+//  * PipeFast  — tuned: shared 1-ulp reciprocals (v_rcp_f64 + 2 Newton steps) instead of IEEE
+//                divisions, explicit FMAs, algebraically equivalent regrouping. Results agree with
+//                the exact path to rounding (tests state the tolerance).
 #pragma once
 
 #include "physics.hpp"
@@ -21,76 +28,84 @@ namespace fused {
 
 struct Out4 { double rho, ua, ut, E; };
 
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT>
-struct Pipe {
+template <int SCHEME_, int LIM_, int PROJ_, int EOS_>
+struct PipeTraits {
+    static constexpr int SCHEME = SCHEME_, LIM = LIM_, PROJ = PROJ_, EOS = EOS_;
     static constexpr int S = (SCHEME == ARMON_SCHEME_GAD) ? 1 : 0;
     static constexpr int W = (PROJ == ARMON_PROJECTION_EULER_2ND) ? 1 : 0;
     static constexpr int LAG = S + W + 2;
+};
 
-    struct Cell { double rho, ua, ut, E, p, rc; };          // pre-sweep state + EOS
+// ======================================================================================================
+// EXACT pipeline
+// ======================================================================================================
+template <int SCHEME, int LIM, int PROJ, int EOS>
+struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
+    using TR = PipeTraits<SCHEME, LIM, PROJ, EOS>;
+    static constexpr int S = TR::S, W = TR::W, LAG = TR::LAG;
+    static constexpr bool kExact = true;
+
+    struct Cell { double rho, ua, ut, E, p, rc; };                 // pre-sweep state + EOS
     struct Upd { double rho, ua, ut, E, q_ua, q_ut, q_E, dxl; };   // Lagrangian (post cell_update) state
 
     double dt, dx, gamma;
-    Cell c0, c1, c2;                              // cells j, j-1, j-2
-    double gus0, gps0, gus1, gps1, gus2, gps2;    // first-order solutions at interfaces j, j-1, j-2
-    double fus0, fps0, fus1, fps1, fus2, fus3;    // final fluxes at interfaces nf, nf-1 (+ older uˢ)
-    Upd l0, l1, l2;                               // updated cells cu, cu-1, cu-2   (cu = nf - 1)
-    double s0[4], s1[4];                          // minmod slopes of cells cu-1, cu-2
-    double a0[4], a1[4];                          // advection fluxes at interfaces na, na-1
+    Cell c[4];                  // ring: cells j, j-1, j-2
+    double gus[4], gps[4];      // ring: first-order solutions at interfaces j, j-1, j-2
+    double fus[4], fps[4];      // ring: final fluxes at interfaces nf .. nf-3
+    Upd l[4];                   // ring: updated cells cu, cu-1, cu-2   (cu = nf - 1)
+    double s[2][4];             // minmod slopes of cells cu-1 / cu-2
+    double a[2][4];             // advection fluxes at interfaces na / na-1
 
     __device__ __forceinline__ Pipe(double dt_, double dx_, double gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
     {
-        // Neutral, finite start values: the first LAG*2 outputs are discarded by the caller.
-        const Cell cz = {1., 0., 0., 1., 1., 1.};
-        c0 = c1 = c2 = cz;
-        gus0 = gus1 = gus2 = 0.; gps0 = gps1 = gps2 = 1.;
-        fus0 = fus1 = fus2 = fus3 = 0.; fps0 = fps1 = 1.;
-        const Upd lz = {1., 0., 0., 1., 0., 0., 1., dx_};
-        l0 = l1 = l2 = lz;
-        for (int k = 0; k < 4; k++) { s0[k] = s1[k] = 0.; a0[k] = a1[k] = 0.; }
-    }
-
-    // EOS of the incoming cell; p and c are also returned for optional materialisation.
-    __device__ __forceinline__ void eos(double rho, double ua, double ut, double E, double& p, double& c) const
-    {
-        if (EOS == ARMON_EOS_BIZARRIUM) {
-            double g_unused;
-            // u² + v² is evaluated as u*u + v*v in the reference: keep (u, v) order for bit parity.
-            phys::bizarrium<false>(rho, E, ua, ut, p, c, g_unused);
-        } else {
-            phys::perfect_gas(gamma, rho, E, ua, ut, p, c);
+        // Neutral, finite start values: the first 2*LAG outputs are discarded by the caller.
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c[k] = Cell{1., 0., 0., 1., 1., 1.};
+            gus[k] = 0.; gps[k] = 1.; fus[k] = 0.; fps[k] = 1.;
+            l[k] = Upd{1., 0., 0., 1., 0., 0., 1., dx_};
+            s[0][k] = s[1][k] = 0.;
+            a[0][k] = a[1][k] = 0.;
         }
     }
 
-    // Feed cell j (pre-sweep state; `uv_swapped`: ua is v and ut is u, i.e. a Y sweep) and get the
-    // post-sweep state of cell j - LAG.
-    template <bool Y_AXIS>
+    // Feed cell j (pre-sweep state; Y_AXIS: ua is v and ut is u) and get the post-sweep state of cell
+    // j - LAG. PH = step index mod 4. p_j, c_j: EOS of cell j, for optional materialisation.
+    template <bool Y_AXIS, int PH>
     __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j)
     {
+        constexpr int R0 = PH & 3, R1 = (PH - 1) & 3, R2 = (PH - 2) & 3, R3 = (PH - 3) & 3;
+        constexpr int P0 = PH & 1, P1 = P0 ^ 1;
+
         // ---- EOS (ref src/kernels.jl:4-55): e = E - 0.5*(u² + v²) with u, v in the reference's order
-        double p, c;
-        if (Y_AXIS) eos(rho, ut, ua, E, p, c); else eos(rho, ua, ut, E, p, c);
+        double p, cs;
+        {
+            const double u = Y_AXIS ? ut : ua, v = Y_AXIS ? ua : ut;
+            if (EOS == ARMON_EOS_BIZARRIUM) {
+                double g_unused;
+                phys::bizarrium<false>(rho, E, u, v, p, cs, g_unused);
+            } else {
+                phys::perfect_gas(gamma, rho, E, u, v, p, cs);
+            }
+        }
         p_j = p;
-        c_j = c;
-        c2 = c1;
-        c1 = c0;
-        c0 = Cell{rho, ua, ut, E, p, rho * c};
+        c_j = cs;
+        c[R0] = Cell{rho, ua, ut, E, p, rho * cs};
+        const Cell& c0 = c[R0];
+        const Cell& c1 = c[R1];
+        const Cell& c2 = c[R2];
 
         // ---- first-order acoustic solve at interface j (ref src/riemann_schemes.jl:21-30)
-        gus2 = gus1; gps2 = gps1;
-        gus1 = gus0; gps1 = gps0;
         {
             const double rc_l = c1.rc, rc_r = c0.rc;
-            gus0 = (rc_l * c1.ua + rc_r * c0.ua + (c1.p - c0.p)) / (rc_l + rc_r);
-            gps0 = (rc_r * c1.p + rc_l * c0.p + rc_l * rc_r * (c1.ua - c0.ua)) / (rc_l + rc_r);
+            gus[R0] = (rc_l * c1.ua + rc_r * c0.ua + (c1.p - c0.p)) / (rc_l + rc_r);
+            gps[R0] = (rc_r * c1.p + rc_l * c0.p + rc_l * rc_r * (c1.ua - c0.ua)) / (rc_l + rc_r);
         }
 
         // ---- final flux at interface nf = j - S
-        fus3 = fus2;
-        fus2 = fus1;
-        fus1 = fus0; fps1 = fps0;
         if (S == 1) {
             // acoustic_GAD! at interface i = j-1: cells i-s = c2, i = c1 (ref src/riemann_schemes.jl:84-104)
+            const double gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
             const double r_um = phys::limiter<LIM>((gus0 - c1.ua) / (gus1 - c2.ua + 1e-6));
             const double r_pm = phys::limiter<LIM>((gps0 - c1.p) / (gps1 - c2.p + 1e-6));
             const double r_up = phys::limiter<LIM>((c2.ua - gus2) / (c1.ua - gus1 + 1e-6));
@@ -99,50 +114,44 @@ struct Pipe {
             const double dm_r = c1.rho * dx;
             const double Dm = (dm_l + dm_r) / 2;
             const double theta = 0.5 * (1 - (c2.rc + c1.rc) / 2 * (dt / Dm));
-            fus0 = gus1 + theta * (r_up * (c1.ua - gus1) - r_um * (gus1 - c2.ua));
-            fps0 = gps1 + theta * (r_pp * (c1.p - gps1) - r_pm * (gps1 - c2.p));
+            fus[R0] = gus1 + theta * (r_up * (c1.ua - gus1) - r_um * (gus1 - c2.ua));
+            fps[R0] = gps1 + theta * (r_pp * (c1.p - gps1) - r_pm * (gps1 - c2.p));
         } else {
-            fus0 = gus0;
-            fps0 = gps0;
+            fus[R0] = gus[R0];
+            fps[R0] = gps[R0];
         }
+        const double fus0 = fus[R0], fps0 = fps[R0], fus1 = fus[R1], fps1 = fps[R1], fus2 = fus[R2], fus3 = fus[R3];
 
         // ---- Lagrangian update of cell cu = nf - 1 (ref src/kernels.jl:58-68)
-        l2 = l1;
-        l1 = l0;
         {
             const Cell& cc = (S == 1) ? c2 : c1;
+            Upd& n = l[R0];
             const double dm = cc.rho * dx;
             const double dxl = dx + dt * (fus0 - fus1);
-            l0.dxl = dxl;
-            l0.rho = dm / dxl;
-            l0.ua = cc.ua + dt / dm * (fps1 - fps0);
-            l0.ut = cc.ut;
-            l0.E = cc.E + dt / dm * (fps1 * fus1 - fps0 * fus0);
-            l0.q_ua = l0.rho * l0.ua;
-            l0.q_ut = l0.rho * l0.ut;
-            l0.q_E = l0.rho * l0.E;
+            n.dxl = dxl;
+            n.rho = dm / dxl;
+            n.ua = cc.ua + dt / dm * (fps1 - fps0);
+            n.ut = cc.ut;
+            n.E = cc.E + dt / dm * (fps1 * fus1 - fps0 * fus0);
+            n.q_ua = n.rho * n.ua;
+            n.q_ut = n.rho * n.ut;
+            n.q_E = n.rho * n.E;
         }
+        const Upd& l0 = l[R0];
+        const Upd& l1 = l[R1];
+        const Upd& l2 = l[R2];
 
-        // ---- advection flux at interface na, projection of cell na - 1
-        for (int k = 0; k < 4; k++) a1[k] = a0[k];
-        Out4 out;
+        // ---- advection flux at interface na (→ a[P0]; a[P1] holds interface na-1), projection of na-1
         if (W == 1) {
-            // slopes of cell cu-1 (ref src/projection_schemes.jl:105-116 evaluated per donor cell)
-            for (int k = 0; k < 4; k++) s1[k] = s0[k];
+            // slopes of cell cu-1 (ref src/projection_schemes.jl:105-116 evaluated per donor cell);
+            // s[P1] still holds the slopes of cell cu-2 from the previous step.
             const double r_m = (2 * l1.dxl) / (l1.dxl + l2.dxl);
             const double r_p = (2 * l1.dxl) / (l1.dxl + l0.dxl);
-            // reference order of the four conserved quantities: ρ, ρu, ρv, ρE
-            if (Y_AXIS) {
-                s0[0] = phys::slope_minmod(l2.rho, l1.rho, l0.rho, r_m, r_p);
-                s0[1] = phys::slope_minmod(l2.q_ut, l1.q_ut, l0.q_ut, r_m, r_p);
-                s0[2] = phys::slope_minmod(l2.q_ua, l1.q_ua, l0.q_ua, r_m, r_p);
-                s0[3] = phys::slope_minmod(l2.q_E, l1.q_E, l0.q_E, r_m, r_p);
-            } else {
-                s0[0] = phys::slope_minmod(l2.rho, l1.rho, l0.rho, r_m, r_p);
-                s0[1] = phys::slope_minmod(l2.q_ua, l1.q_ua, l0.q_ua, r_m, r_p);
-                s0[2] = phys::slope_minmod(l2.q_ut, l1.q_ut, l0.q_ut, r_m, r_p);
-                s0[3] = phys::slope_minmod(l2.q_E, l1.q_E, l0.q_E, r_m, r_p);
-            }
+            // reference order of the conserved quantities: ρ, ρu, ρv, ρE
+            s[P0][0] = phys::slope_minmod(l2.rho, l1.rho, l0.rho, r_m, r_p);
+            s[P0][Y_AXIS ? 2 : 1] = phys::slope_minmod(l2.q_ua, l1.q_ua, l0.q_ua, r_m, r_p);
+            s[P0][Y_AXIS ? 1 : 2] = phys::slope_minmod(l2.q_ut, l1.q_ut, l0.q_ut, r_m, r_p);
+            s[P0][3] = phys::slope_minmod(l2.q_E, l1.q_E, l0.q_E, r_m, r_p);
             // interface is = cu-1 (ref :92-124): upwind donor cell and its slopes
             const double disp = dt * fus2;
             const bool up = disp > 0;
@@ -150,35 +159,35 @@ struct Pipe {
             const double Dxe = up ? -(dx - dt * fus3) : (dx + dt * fus1);
             const double lf = Dxe / (2 * d.dxl);
             const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
-            a0[0] = disp * (d.rho - (up ? s1[0] : s0[0]) * lf);
-            a0[1] = disp * (q1 - (up ? s1[1] : s0[1]) * lf);
-            a0[2] = disp * (q2 - (up ? s1[2] : s0[2]) * lf);
-            a0[3] = disp * (d.q_E - (up ? s1[3] : s0[3]) * lf);
-            out = project<Y_AXIS>(l2);
+            a[P0][0] = disp * (d.rho - (up ? s[P1][0] : s[P0][0]) * lf);
+            a[P0][1] = disp * (q1 - (up ? s[P1][1] : s[P0][1]) * lf);
+            a[P0][2] = disp * (q2 - (up ? s[P1][2] : s[P0][2]) * lf);
+            a[P0][3] = disp * (d.q_E - (up ? s[P1][3] : s[P0][3]) * lf);
+            return project<Y_AXIS, P0>(l2);
         } else {
             // advection_first_order! at interface is = cu (ref src/projection_schemes.jl:62-78)
             const double disp = dt * fus1;
             const Upd& d = (disp > 0) ? l1 : l0;
             const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
-            a0[0] = disp * d.rho;
-            a0[1] = disp * q1;
-            a0[2] = disp * q2;
-            a0[3] = disp * d.q_E;
-            out = project<Y_AXIS>(l1);
+            a[P0][0] = disp * d.rho;
+            a[P0][1] = disp * q1;
+            a[P0][2] = disp * q2;
+            a[P0][3] = disp * d.q_E;
+            return project<Y_AXIS, P0>(l1);
         }
-        return out;
     }
 
-    // euler_projection! of cell o with A_o = a1, A_{o+1} = a0 (ref src/projection_schemes.jl:23-41)
-    template <bool Y_AXIS>
-    __device__ __forceinline__ Out4 project(const Upd& l) const
+    // euler_projection! of cell o with A_o = a[P1], A_{o+1} = a[P0] (ref src/projection_schemes.jl:23-41)
+    template <bool Y_AXIS, int P0>
+    __device__ __forceinline__ Out4 project(const Upd& lo) const
     {
-        const double dX = l.dxl;
-        const double u = Y_AXIS ? l.ut : l.ua, v = Y_AXIS ? l.ua : l.ut;   // reference's (u, v)
-        const double t_rho  = (dX * l.rho       - (a0[0] - a1[0])) / dx;
-        const double t_urho = (dX * l.rho * u   - (a0[1] - a1[1])) / dx;
-        const double t_vrho = (dX * l.rho * v   - (a0[2] - a1[2])) / dx;
-        const double t_Erho = (dX * l.rho * l.E - (a0[3] - a1[3])) / dx;
+        constexpr int P1 = P0 ^ 1;
+        const double dX = lo.dxl;
+        const double u = Y_AXIS ? lo.ut : lo.ua, v = Y_AXIS ? lo.ua : lo.ut;   // reference's (u, v)
+        const double t_rho  = (dX * lo.rho        - (a[P0][0] - a[P1][0])) / dx;
+        const double t_urho = (dX * lo.rho * u    - (a[P0][1] - a[P1][1])) / dx;
+        const double t_vrho = (dX * lo.rho * v    - (a[P0][2] - a[P1][2])) / dx;
+        const double t_Erho = (dX * lo.rho * lo.E - (a[P0][3] - a[P1][3])) / dx;
         Out4 o;
         o.rho = t_rho;
         const double un = t_urho / t_rho, vn = t_vrho / t_rho;
@@ -186,6 +195,251 @@ struct Pipe {
         o.ut = Y_AXIS ? un : vn;
         o.E = t_Erho / t_rho;
         return o;
+    }
+};
+
+// ======================================================================================================
+// tuned pipeline
+// ======================================================================================================
+namespace fast {
+
+// 1/x to ≈1 ulp: v_rcp_f64 (2^-24) + two Newton steps. No scaling/fixup: operands here are O(1) state.
+__device__ __forceinline__ double rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// sqrt(x) to ≈1-2 ulp: v_rsq_f64 + two coupled Newton (Goldschmidt) steps; sqrt(0) = 0.
+__device__ __forceinline__ double sqrt_(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, r, g);
+    return (x == 0.) ? 0. : g;
+}
+
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <int LIM>
+__device__ __forceinline__ double limiter(double r)
+{
+    if (LIM == ARMON_LIMITER_MINMOD) return __builtin_fmax(0., __builtin_fmin(1., r));
+    if (LIM == ARMON_LIMITER_SUPERBEE)
+        return __builtin_fmax(__builtin_fmax(0., __builtin_fmin(2. * r, 1.)), __builtin_fmin(r, 2.));
+    return 1.;
+}
+
+// minmod(a, b) = sign·min(|a|,|b|) when a·b > 0, else 0  (== slope_minmod of ref projection_schemes.jl:15-20)
+__device__ __forceinline__ double minmod(double a, double b)
+{
+    return __builtin_fmax(0., __builtin_fmin(a, b)) + __builtin_fmin(0., __builtin_fmax(a, b));
+}
+
+}  // namespace fast
+
+template <int SCHEME, int LIM, int PROJ, int EOS>
+struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
+    using TR = PipeTraits<SCHEME, LIM, PROJ, EOS>;
+    static constexpr int S = TR::S, W = TR::W, LAG = TR::LAG;
+    static constexpr bool kExact = false;
+
+    struct Cell { double rho, ua, ut, E, p, rc; };
+    // Lagrangian state: q_* = ρ·(ua, ut, E); hinv = 0.5/dxl; d_* = q(this) - q(previous cell)
+    struct Upd { double rho, q_ua, q_ut, q_E, dxl, hinv, d_rho, d_ua, d_ut, d_E; };
+
+    double dt, dx, gamma, inv_dx, dt_dx, gm1, ggm1;
+    Cell c[4];
+    double gus[4], gps[4], src[4];          // first-order solutions + (rc_l + rc_r) of the interface
+    double fps[4], dtu[4], pu[4];           // final flux: pˢ, dt·uˢ, pˢ·uˢ at interfaces nf .. nf-3
+    Upd l[4];
+    double isum[2];                         // 1 / (dxl[cu] + dxl[cu-1]) of this / the previous step
+    double s[2][4];
+    double a[2][4];
+
+    __device__ __forceinline__ PipeFast(double dt_, double dx_, double gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
+    {
+        inv_dx = 1. / dx_;
+        dt_dx = dt_ / dx_;
+        gm1 = gamma_ - 1.;
+        ggm1 = gamma_ * (gamma_ - 1.);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c[k] = Cell{1., 0., 0., 1., 1., 1.};
+            gus[k] = 0.; gps[k] = 1.; src[k] = 2.;
+            fps[k] = 1.; dtu[k] = 0.; pu[k] = 0.;
+            l[k] = Upd{1., 0., 0., 1., dx_, 0.5 / dx_, 0., 0., 0., 0.};
+            s[0][k] = s[1][k] = 0.;
+            a[0][k] = a[1][k] = 0.;
+        }
+        isum[0] = isum[1] = 0.5 / dx_;
+    }
+
+    template <bool Y_AXIS, int PH>
+    __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j)
+    {
+        using namespace fast;
+        constexpr int R0 = PH & 3, R1 = (PH - 1) & 3, R2 = (PH - 2) & 3, R3 = (PH - 3) & 3;
+        constexpr int P0 = PH & 1, P1 = P0 ^ 1;
+
+        // ---- EOS
+        double p, cs;
+        if (EOS == ARMON_EOS_BIZARRIUM) {
+            bizarrium_fast(rho, ua, ut, E, p, cs);
+        } else {
+            // p = (γ-1)ρe, c = sqrt(γp/ρ) = sqrt(γ(γ-1)e): no division
+            const double e = fma_(-0.5, fma_(ua, ua, ut * ut), E);
+            p = gm1 * rho * e;
+            cs = sqrt_(ggm1 * e);
+        }
+        p_j = p;
+        c_j = cs;
+        c[R0] = Cell{rho, ua, ut, E, p, rho * cs};
+        const Cell& c0 = c[R0];
+        const Cell& c1 = c[R1];
+        const Cell& c2 = c[R2];
+
+        // ---- first-order acoustic solve at interface j: one shared reciprocal
+        {
+            const double rc_l = c1.rc, rc_r = c0.rc;
+            const double sum = rc_l + rc_r;
+            const double inv = rcp(sum);
+            src[R0] = sum;
+            gus[R0] = fma_(rc_l, c1.ua, fma_(rc_r, c0.ua, c1.p - c0.p)) * inv;
+            gps[R0] = fma_(rc_r, c1.p, fma_(rc_l, c0.p, rc_l * rc_r * (c1.ua - c0.ua))) * inv;
+        }
+
+        // ---- final flux at interface nf = j - S
+        double fus0;
+        if (S == 1) {
+            const double gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
+            const double Au = gus1 - c2.ua, Bu = c1.ua - gus1;     // (uˢ_i - u[i-s]), (u[i] - uˢ_i)
+            const double Ap = gps1 - c2.p, Bp = c1.p - gps1;
+            const double r_um = limiter<LIM>((gus0 - c1.ua) * rcp(Au + 1e-6));
+            const double r_pm = limiter<LIM>((gps0 - c1.p) * rcp(Ap + 1e-6));
+            const double r_up = limiter<LIM>((c2.ua - gus2) * rcp(Bu + 1e-6));
+            const double r_pp = limiter<LIM>((c2.p - gps2) * rcp(Bp + 1e-6));
+            // θ = ½(1 - (rc_l+rc_r)/2 · dt/Dm), Dm = dx(ρ_l+ρ_r)/2  →  ½ - ½·(rc_l+rc_r)·(dt/dx)/(ρ_l+ρ_r)
+            const double theta = fma_(-0.5 * src[R1] * dt_dx, rcp(c2.rho + c1.rho), 0.5);
+            fus0 = fma_(theta, fma_(r_up, Bu, -r_um * Au), gus1);
+            fps[R0] = fma_(theta, fma_(r_pp, Bp, -r_pm * Ap), gps1);
+        } else {
+            fus0 = gus[R0];
+            fps[R0] = gps[R0];
+        }
+        dtu[R0] = dt * fus0;
+        pu[R0] = fps[R0] * fus0;
+        const double fps0 = fps[R0], fps1 = fps[R1];
+
+        // ---- Lagrangian update of cell cu = nf - 1
+        {
+            const Cell& cc = (S == 1) ? c2 : c1;
+            Upd& n = l[R0];
+            const Upd& prev = l[R1];
+            const double dtdm = dt_dx * rcp(cc.rho);             // dt / (ρ dx)
+            const double dxl = (dx + dtu[R0]) - dtu[R1];
+            const double inv_dxl = rcp(dxl);
+            n.dxl = dxl;
+            n.hinv = 0.5 * inv_dxl;
+            n.rho = cc.rho * dx * inv_dxl;
+            const double ua_n = fma_(dtdm, fps1 - fps0, cc.ua);
+            const double E_n = fma_(dtdm, pu[R1] - pu[R0], cc.E);
+            n.q_ua = n.rho * ua_n;
+            n.q_ut = n.rho * cc.ut;
+            n.q_E = n.rho * E_n;
+            n.d_rho = n.rho - prev.rho;
+            n.d_ua = n.q_ua - prev.q_ua;
+            n.d_ut = n.q_ut - prev.q_ut;
+            n.d_E = n.q_E - prev.q_E;
+        }
+        const Upd& l0 = l[R0];
+        const Upd& l1 = l[R1];
+        const Upd& l2 = l[R2];
+
+        if (W == 1) {
+            // slopes of cell cu-1: r₊ = 2Δx/(Δx+Δx₊), r₋ = 2Δx/(Δx+Δx₋); the second sum is last step's first
+            isum[P0] = rcp(l1.dxl + l0.dxl);
+            const double two_dxl = 2. * l1.dxl;
+            const double r_p = two_dxl * isum[P0], r_m = two_dxl * isum[P1];
+            s[P0][0] = minmod(r_p * l0.d_rho, r_m * l1.d_rho);
+            s[P0][Y_AXIS ? 2 : 1] = minmod(r_p * l0.d_ua, r_m * l1.d_ua);
+            s[P0][Y_AXIS ? 1 : 2] = minmod(r_p * l0.d_ut, r_m * l1.d_ut);
+            s[P0][3] = minmod(r_p * l0.d_E, r_m * l1.d_E);
+            // interface is = cu-1
+            const double disp = dtu[R2];
+            const bool up = disp > 0;
+            const Upd& d = up ? l2 : l1;
+            const double Dxe = up ? (dtu[R3] - dx) : (dx + dtu[R1]);
+            const double lf = Dxe * d.hinv;
+            const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
+            a[P0][0] = disp * fma_(-(up ? s[P1][0] : s[P0][0]), lf, d.rho);
+            a[P0][1] = disp * fma_(-(up ? s[P1][1] : s[P0][1]), lf, q1);
+            a[P0][2] = disp * fma_(-(up ? s[P1][2] : s[P0][2]), lf, q2);
+            a[P0][3] = disp * fma_(-(up ? s[P1][3] : s[P0][3]), lf, d.q_E);
+            return project<Y_AXIS, P0>(l2);
+        } else {
+            const double disp = dtu[R1];
+            const Upd& d = (disp > 0) ? l1 : l0;
+            const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
+            a[P0][0] = disp * d.rho;
+            a[P0][1] = disp * q1;
+            a[P0][2] = disp * q2;
+            a[P0][3] = disp * d.q_E;
+            return project<Y_AXIS, P0>(l1);
+        }
+    }
+
+    // (dX·q - ΔA)/dx, then u = ρu/ρ …: the 1/dx cancels in the three ratios
+    template <bool Y_AXIS, int P0>
+    __device__ __forceinline__ Out4 project(const Upd& lo) const
+    {
+        using namespace fast;
+        constexpr int P1 = P0 ^ 1;
+        const double dX = lo.dxl;
+        const double q1 = Y_AXIS ? lo.q_ut : lo.q_ua, q2 = Y_AXIS ? lo.q_ua : lo.q_ut;
+        const double T_rho = fma_(dX, lo.rho, a[P1][0] - a[P0][0]);
+        const double T_u = fma_(dX, q1, a[P1][1] - a[P0][1]);
+        const double T_v = fma_(dX, q2, a[P1][2] - a[P0][2]);
+        const double T_E = fma_(dX, lo.q_E, a[P1][3] - a[P0][3]);
+        const double inv = rcp(T_rho);
+        Out4 o;
+        o.rho = T_rho * inv_dx;
+        const double un = T_u * inv, vn = T_v * inv;
+        o.ua = Y_AXIS ? vn : un;
+        o.ut = Y_AXIS ? un : vn;
+        o.E = T_E * inv;
+        return o;
+    }
+
+    // ref src/kernels.jl:16-55 with the four divisions by (1 - s·x) and the two by ρ shared
+    __device__ __forceinline__ void bizarrium_fast(double rho, double ua, double ut, double E, double& p, double& cs) const
+    {
+        using namespace fast;
+        const double rho0 = 10000., K0 = 1e+11, Cv0 = 1000., T0 = 300., eps0 = 0., G0 = 1.5, s_ = 1.5;
+        const double q = -42080895. / 14941154., rr = 727668333. / 149411540.;
+        const double inv_rho = rcp(rho);
+        const double x = rho * (1. / rho0) - 1.;
+        const double G = G0 * (1. - rho0 * inv_rho);
+        const double x2 = x * x, x3 = x2 * x;
+        const double opx = 1. + x, opx2 = opx * opx, opx3 = opx2 * opx;
+        const double inv_d = rcp(1. - s_ * x);
+        const double f0 = (1. + (s_ / 3. - 2.) * x + q * x2 + rr * x3) * inv_d;
+        const double f1 = (s_ / 3. - 2. + 2. * q * x + 3. * rr * x2 + s_ * f0) * inv_d;
+        const double f2 = (2. * q + 6. * rr * x + 2. * s_ * f1) * inv_d;
+        const double epsk0 = eps0 - Cv0 * T0 * (1. + G) + 0.5 * (K0 / rho0) * x2 * f0;
+        const double pk0 = -Cv0 * T0 * G0 * rho0 + 0.5 * K0 * x * opx2 * (2. * f0 + x * f1);
+        const double pk0prime = -0.5 * K0 * opx3 * rho0 *
+                                (2. * (1. + 3. * x) * f0 + 2. * x * (2. + 3. * x) * f1 + x2 * opx * f2);
+        const double e = fma_(-0.5, fma_(ua, ua, ut * ut), E);
+        p = pk0 + G0 * rho0 * (e - epsk0);
+        cs = sqrt_(G0 * rho0 * (p - pk0) - pk0prime) * inv_rho;
     }
 };
 
