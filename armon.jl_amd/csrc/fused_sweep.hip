@@ -68,49 +68,53 @@ __global__ void __launch_bounds__(kYBlock)
 k_sweep_y(sweep_args a)
 {
     constexpr int LAG = PIPE::LAG;
+    constexpr int PF = 4;            // rows in flight per lane (= the unroll of the march)
     const int64_t x = (int64_t)blockIdx.x * kYBlock + threadIdx.x;
     if (x >= a.nx) return;
     const int64_t o0 = (int64_t)blockIdx.y * a.seg;
     const int64_t o1 = (o0 + a.seg < a.ny) ? o0 + a.seg : a.ny;
-    const int64_t col = x + a.g;
+    const unsigned col = (unsigned)(x + a.g);    // 32-bit lane offset; row bases stay scalar
 
     PIPE pipe(a.dt, a.dx, a.gamma);
 
     const int64_t j_begin = o0 - LAG, j_end = o1 + LAG;
-    double n_rho, n_ua, n_ut, n_E;
+    double pr[PF][4];                // prefetch ring: (ρ, ua, ut, E) of rows j .. j+PF-1
     // Loads one row of this lane's column (clamped to the run so that padding steps stay in bounds).
-    auto load = [&](int64_t j) {
+    auto load = [&](auto slot, int64_t j) {
+        constexpr int K = decltype(slot)::value;
         double fa, ft;
         const int64_t jc = j < j_end ? j : j_end - 1;
-        const int64_t src = bc_source(a, a.ny, jc, fa, ft);
-        const int64_t idx = (src + a.g) * a.row_len + col;
-        n_rho = a.rho_in[idx];
-        n_ua = a.ua_in[idx] * fa;
-        n_ut = a.ut_in[idx] * ft;
-        n_E = a.E_in[idx];
+        const int64_t row = (bc_source(a, a.ny, jc, fa, ft) + a.g) * a.row_len;   // uniform
+        pr[K][0] = (a.rho_in + row)[col];
+        pr[K][1] = (a.ua_in + row)[col] * fa;
+        pr[K][2] = (a.ut_in + row)[col] * ft;
+        pr[K][3] = (a.E_in + row)[col];
     };
     auto step = [&](auto ph, int64_t j) {
         constexpr int PH = decltype(ph)::value;
-        const double rho = n_rho, ua = n_ua, ut = n_ut, E = n_E;
-        load(j + 1);   // software prefetch of the next row while this one is computed
+        const double rho = pr[PH][0], ua = pr[PH][1], ut = pr[PH][2], E = pr[PH][3];
+        load(ph, j + PF);            // refill this slot: PF rows ahead of the march
         double p, c;
         const fused::Out4 out = pipe.template push<true, PH>(rho, ua, ut, E, p, c);
         if (a.emit && j >= o0 && j < o1) {
-            const int64_t ij = (j + a.g) * a.row_len + col;
-            if (a.emit & 1) a.p_out[ij] = p;
-            if (a.emit & 2) a.c_out[ij] = c;
+            const int64_t row = (j + a.g) * a.row_len;
+            if (a.emit & 1) (a.p_out + row)[col] = p;
+            if (a.emit & 2) (a.c_out + row)[col] = c;
         }
         const int64_t o = j - LAG;
         if (o >= o0 && o < o1) {
-            const int64_t io = (o + a.g) * a.row_len + col;
-            a.rho_out[io] = out.rho;
-            a.ua_out[io] = out.ua;
-            a.ut_out[io] = out.ut;
-            a.E_out[io] = out.E;
+            const int64_t row = (o + a.g) * a.row_len;
+            (a.rho_out + row)[col] = out.rho;
+            (a.ua_out + row)[col] = out.ua;
+            (a.ut_out + row)[col] = out.ut;
+            (a.E_out + row)[col] = out.E;
         }
     };
 
-    load(j_begin);
+    load(std::integral_constant<int, 0>{}, j_begin);
+    load(std::integral_constant<int, 1>{}, j_begin + 1);
+    load(std::integral_constant<int, 2>{}, j_begin + 2);
+    load(std::integral_constant<int, 3>{}, j_begin + 3);
     // The march is unrolled by the 4 phases of the pipeline's history rings.
     for (int64_t j = j_begin; j < j_end; j += 4) {
         step(std::integral_constant<int, 0>{}, j);
@@ -213,6 +217,129 @@ k_sweep_x(sweep_args a)
     }
 }
 
+// Vectorised X sweep for even row pitch (16-B aligned column pairs): CH = 16 columns per chunk = one
+// 128-B line per row and array, 16-B loads/stores, and the NEXT chunk's 32 loads are issued into registers
+// before the march over the current chunk starts, so a single wave per SIMD keeps ~32 KB in flight.
+constexpr int kXVecChunk = 16;
+
+template <class PIPE, int CH>
+__global__ void __launch_bounds__(kXRows, 1)
+k_sweep_x_vec(sweep_args a)
+{
+    constexpr int LAG = PIPE::LAG;
+    constexpr int PITCH = CH + 2;                 // even pitch: 16-B aligned pairs for the row phases
+    constexpr int LPR = CH / 2;                   // lanes per row in the row phases (16 B each)
+    constexpr int RPI = kXRows / LPR;             // rows per wave-wide access
+    constexpr int NI = kXRows / RPI;              // accesses per array and chunk
+    constexpr bool VEC_STORE = (LAG % 2) == 0;    // output column pairs are 16-B aligned only for even LAG
+    __shared__ double2 tile2[4 * kXRows * PITCH / 2];
+    double* tile = reinterpret_cast<double*>(tile2);
+
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * kXRows;
+    const int64_t o0 = (int64_t)blockIdx.x * a.seg;
+    const int64_t o1 = (o0 + a.seg < a.nx) ? o0 + a.seg : a.nx;
+    const int64_t j_begin = o0 - LAG - ((a.g - LAG) & 1);   // (j_begin + g) even → aligned pairs
+    const int64_t j_end = o1 + LAG;
+    const bool row_ok = (r0 + lane) < a.ny;
+    const int sub_row = lane / LPR, sub_pair = lane % LPR;
+    const double* in[4] = {a.rho_in, a.ua_in, a.ut_in, a.E_in};
+    double* out[4] = {a.rho_out, a.ua_out, a.ut_out, a.E_out};
+
+    auto T = [&](int plane, int r, int t) -> double& { return tile[(plane * kXRows + r) * PITCH + t]; };
+
+    PIPE pipe(a.dt, a.dx, a.gamma);
+    double2 R[4][NI];
+
+    // One element with boundary handling (edge chunks only).
+    auto elem = [&](int f, int64_t row, int64_t j) -> double {
+        double fa, ft;
+        const int64_t jc = j < j_end ? j : j_end - 1;
+        const int64_t src = bc_source(a, a.nx, jc, fa, ft);
+        const double v = in[f][(row + a.g) * a.row_len + (src + a.g)];
+        return f == 1 ? v * fa : (f == 2 ? v * ft : v);
+    };
+    auto load_chunk = [&](int64_t jb) {
+        const int64_t j = jb + 2 * sub_pair;
+        const bool interior = jb >= 0 && jb + CH <= a.nx;      // uniform
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int64_t row = r0 + k * RPI + sub_row;
+            if (row < a.ny) {
+                if (interior) {
+                    const int64_t idx = (row + a.g) * a.row_len + (j + a.g);
+#pragma unroll
+                    for (int f = 0; f < 4; f++) R[f][k] = *reinterpret_cast<const double2*>(in[f] + idx);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 4; f++) R[f][k] = double2{elem(f, row, j), elem(f, row, j + 1)};
+                }
+            }
+        }
+    };
+
+    load_chunk(j_begin);
+    for (int64_t jb = j_begin; jb < j_end; jb += CH) {
+        // -- registers → LDS tile
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int r = k * RPI + sub_row;
+#pragma unroll
+            for (int f = 0; f < 4; f++) *reinterpret_cast<double2*>(&T(f, r, 2 * sub_pair)) = R[f][k];
+        }
+        __syncthreads();
+        // -- prefetch the next chunk while this one is marched over
+        if (jb + CH < j_end) load_chunk(jb + CH);
+        // -- march: lane walks its own row through the tile, results overwrite the consumed slots
+        if (row_ok) {
+#pragma unroll 1
+            for (int t0 = 0; t0 < CH; t0 += 4) {
+                static_for(std::make_integer_sequence<int, 4>{}, [&](auto phc) {
+                    constexpr int PH = decltype(phc)::value;
+                    const int t = t0 + PH;
+                    if (jb + t < j_end) {
+                        double p, c;
+                        const fused::Out4 o = pipe.template push<false, PH>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c);
+                        T(0, lane, t) = o.rho;
+                        T(1, lane, t) = o.ua;
+                        T(2, lane, t) = o.ut;
+                        T(3, lane, t) = o.E;
+                    }
+                });
+            }
+        }
+        __syncthreads();
+        // -- store phase: slot t holds the new state of column jb + t - LAG
+        {
+            const int64_t o = jb + 2 * sub_pair - LAG;
+            const bool interior = VEC_STORE && (jb - LAG >= o0) && (jb + CH - LAG <= o1);   // uniform
+#pragma unroll
+            for (int k = 0; k < NI; k++) {
+                const int r = k * RPI + sub_row;
+                const int64_t row = r0 + r;
+                if (row < a.ny) {
+                    const int64_t io = (row + a.g) * a.row_len + (o + a.g);
+                    if (interior) {
+#pragma unroll
+                        for (int f = 0; f < 4; f++)
+                            *reinterpret_cast<double2*>(out[f] + io) = *reinterpret_cast<const double2*>(&T(f, r, 2 * sub_pair));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const int64_t oe = o + e;
+                            if (oe >= o0 && oe < o1 && jb + 2 * sub_pair + e < j_end) {
+#pragma unroll
+                                for (int f = 0; f < 4; f++) out[f][io + e] = T(f, r, 2 * sub_pair + e);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 constexpr int kXChunk = 8;
 
 template <class PIPE>
@@ -224,6 +351,14 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis)
         return check_launch("sweep_y");
     }
     dim3 grid((unsigned)((a.nx + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
+    const auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec_ok = !a.emit && (a.row_len % 2 == 0) && aligned16(a.rho_in) && aligned16(a.ua_in) &&
+                        aligned16(a.ut_in) && aligned16(a.E_in) && aligned16(a.rho_out) && aligned16(a.ua_out) &&
+                        aligned16(a.ut_out) && aligned16(a.E_out);
+    if (vec_ok) {
+        hipLaunchKernelGGL((k_sweep_x_vec<PIPE, kXVecChunk>), grid, dim3(kXRows), 0, ctx->stream, a);
+        return check_launch("sweep_x_vec");
+    }
     const size_t lds = (size_t)(a.emit ? 6 : 4) * kXRows * (kXChunk + 1) * sizeof(double);
     hipLaunchKernelGGL((k_sweep_x<PIPE, kXChunk>), grid, dim3(kXRows), lds, ctx->stream, a);
     return check_launch("sweep_x");

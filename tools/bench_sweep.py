@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Time armon_hip_sweep per axis / arithmetic on one GPU with HIP events (interleaved rounds, one process).
+
+    python tools/bench_sweep.py [--n 16384] [--rounds 5] [--test Sod] [--scheme GAD] [--emit]
+"""
+import argparse
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import armon_amd
+from armon_amd.blocking import Axis
+from armon_amd.solver import BlockGrid, fused_sweep, init_test, update_EOS
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=16384)
+ap.add_argument("--ny", type=int, default=0)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--test", default="Sod")
+ap.add_argument("--scheme", default="GAD")
+ap.add_argument("--projection", default="euler_2nd")
+ap.add_argument("--emit", action="store_true")
+ap.add_argument("--modes", default="exact,fast")
+args = ap.parse_args()
+ny = args.ny or args.n
+
+params = armon_amd.ArmonParameters(test=args.test, N=(args.n, ny), scheme=args.scheme, projection=args.projection,
+                                   silent=5, maxcycle=10)
+grid = BlockGrid(params)
+init_test(params, grid)
+dev = params.device
+dx = params.domain_size[0] / args.n
+dt = 0.3 * dx          # a plausible CFL-limited step for Sod (c ~ 1.2)
+cells = args.n * ny
+res = {}
+for r in range(args.rounds + 1):
+    for mode in args.modes.split(","):
+        params.exact_arithmetic = mode == "exact"
+        for axis in (Axis.X, Axis.Y):
+            dev.event_record(0)
+            fused_sweep(params, grid, axis, dt, dx, emit_p=args.emit, emit_c=args.emit)
+            dev.event_record(1)
+            ms = dev.event_elapsed_ms(0, 1)
+            if r > 0:
+                res.setdefault((mode, axis.name), []).append(ms)
+    # keep the state sane (a few sweeps of Sod are harmless, but do not let it drift for long)
+    if r % 3 == 2:
+        init_test(params, grid)
+for (mode, axis), v in res.items():
+    med = statistics.median(v)
+    print(f"{mode:5s} sweep_{axis}: median {med:7.3f} ms  min {min(v):7.3f} ms   "
+          f"{64 * cells / med / 1e6:7.1f} GB/s algorithmic   {cells / med / 1e3:8.1f} Mcells/s")
