@@ -13,6 +13,7 @@
 // Redundant work is confined to the LAG (≤4) cells at both ends of a run.
 #include "common.hpp"
 #include "sweep_pipeline.hpp"
+#include "sweep_spatial.hpp"
 
 #include <type_traits>
 #include <utility>
@@ -27,6 +28,7 @@ struct sweep_args {
     int32_t bc_low, bc_high;       // mirror BC applied in-kernel on that side of the sweep axis
     int32_t emit;                  // bit 0: write p_out, bit 1: write c_out
     int64_t seg;                   // cells per run along the sweep axis
+    int32_t x_kernel;              // X sweep form: 0 spatial (DPP), 1 LDS-transposed march (vector), 2 generic march
     double dt, dx, gamma;
     double fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const double *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
@@ -217,6 +219,100 @@ k_sweep_x(sweep_args a)
     }
 }
 
+// ---- X sweep, spatial form (lanes along x, DPP neighbour exchange) -------------------------------------
+// blockDim = (64, kXSRows): one wave per row, kXSRows consecutive rows per workgroup. Each wave walks
+// NITER strips of 64*K cells along its row; a strip yields 64*K - 2*HALO new cells.
+constexpr int kXSRows = 4;
+
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K>
+__global__ void __launch_bounds__(64 * kXSRows)
+k_sweep_x_dpp(sweep_args a, int niter)
+{
+    using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, K>;
+    using St = fused::Strip<K>;
+    constexpr int LAG = SW::LAG;
+    constexpr int HALO = (K == 1) ? LAG : ((LAG + 1) & ~1);   // even for K = 2: strips stay pair-aligned
+    constexpr int WIDTH = 64 * K;
+    constexpr int STRIDE = WIDTH - 2 * HALO;
+
+    const int lane = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.y * kXSRows + threadIdx.y;
+    if (row >= a.ny) return;                       // whole wave
+    const int64_t row_off = (row + a.g) * a.row_len + a.g;
+    const double* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
+    double* out[4] = {a.rho_out + row_off, a.ua_out + row_off, a.ut_out + row_off, a.E_out + row_off};
+    const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && (a.g % 2 == 0);   // uniform
+
+    SW sw{a.dt, a.dx, a.gamma};
+
+    const int64_t w_first = (int64_t)blockIdx.x * niter * STRIDE;
+    for (int it = 0; it < niter; it++) {
+        const int64_t w0 = w_first + (int64_t)it * STRIDE;    // first cell this strip produces
+        if (w0 >= a.nx) break;
+        const int64_t cb = w0 - HALO;                         // first cell of the strip
+        const int64_t j0 = cb + (int64_t)lane * K;            // this lane's first cell
+
+        St rho, ua, ut, E;
+        const bool interior = cb >= 0 && cb + WIDTH <= a.nx;  // uniform: no ghost, no clamping
+        if (interior && (K == 1 || vec_ok)) {
+            if (K == 2) {
+                const double2 r = *reinterpret_cast<const double2*>(in[0] + j0);
+                const double2 u = *reinterpret_cast<const double2*>(in[1] + j0);
+                const double2 v = *reinterpret_cast<const double2*>(in[2] + j0);
+                const double2 e = *reinterpret_cast<const double2*>(in[3] + j0);
+                rho.v[0] = r.x; rho.v[K - 1] = r.y;
+                ua.v[0] = u.x; ua.v[K - 1] = u.y;
+                ut.v[0] = v.x; ut.v[K - 1] = v.y;
+                E.v[0] = e.x; E.v[K - 1] = e.y;
+            } else {
+                rho.v[0] = in[0][j0]; ua.v[0] = in[1][j0]; ut.v[0] = in[2][j0]; E.v[0] = in[3][j0];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                // clamp into the block (ghosts included), then mirror physical boundaries
+                int64_t j = j0 + k;
+                j = j < -(int64_t)a.g ? -(int64_t)a.g : (j > a.nx + a.g - 1 ? a.nx + a.g - 1 : j);
+                double fa, ft;
+                const int64_t src = bc_source(a, a.nx, j, fa, ft);
+                rho.v[k] = in[0][src];
+                ua.v[k] = in[1][src] * fa;
+                ut.v[k] = in[2][src] * ft;
+                E.v[k] = in[3][src];
+            }
+        }
+
+        St o_rho, o_u, o_v, o_E, p, cs;
+        sw.run(rho, ua, ut, E, o_rho, o_u, o_v, o_E, p, cs);
+
+        // cells this lane may store: inside the strip's valid window and inside the block
+        const int64_t hi = (w0 + STRIDE < a.nx) ? w0 + STRIDE : a.nx;
+        if (K == 2 && vec_ok && j0 >= w0 && j0 + 1 < hi) {
+            *reinterpret_cast<double2*>(out[0] + j0) = double2{o_rho.v[0], o_rho.v[K - 1]};
+            *reinterpret_cast<double2*>(out[1] + j0) = double2{o_u.v[0], o_u.v[K - 1]};
+            *reinterpret_cast<double2*>(out[2] + j0) = double2{o_v.v[0], o_v.v[K - 1]};
+            *reinterpret_cast<double2*>(out[3] + j0) = double2{o_E.v[0], o_E.v[K - 1]};
+            if (a.emit) {
+                if (a.emit & 1) *reinterpret_cast<double2*>(a.p_out + row_off + j0) = double2{p.v[0], p.v[K - 1]};
+                if (a.emit & 2) *reinterpret_cast<double2*>(a.c_out + row_off + j0) = double2{cs.v[0], cs.v[K - 1]};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int64_t j = j0 + k;
+                if (j >= w0 && j < hi) {
+                    out[0][j] = o_rho.v[k];
+                    out[1][j] = o_u.v[k];
+                    out[2][j] = o_v.v[k];
+                    out[3][j] = o_E.v[k];
+                    if (a.emit & 1) (a.p_out + row_off)[j] = p.v[k];
+                    if (a.emit & 2) (a.c_out + row_off)[j] = cs.v[k];
+                }
+            }
+        }
+    }
+}
+
 // Vectorised X sweep for even row pitch (16-B aligned column pairs): CH = 16 columns per chunk = one
 // 128-B line per row and array, 16-B loads/stores, and the NEXT chunk's 32 loads are issued into registers
 // before the march over the current chunk starts, so a single wave per SIMD keeps ~32 KB in flight.
@@ -342,9 +438,21 @@ k_sweep_x_vec(sweep_args a)
 
 constexpr int kXChunk = 8;
 
+constexpr int kXSK = 2;          // cells per lane of the spatial X sweep
+constexpr int kXSNiter = 8;      // strips per wave
+
 template <class PIPE>
 int launch(armon_ctx* ctx, const sweep_args& a, int axis)
 {
+    if (axis == ARMON_AXIS_X && a.x_kernel == 0) {
+        constexpr int halo = (kXSK == 1) ? PIPE::LAG : ((PIPE::LAG + 1) & ~1);
+        constexpr int stride = 64 * kXSK - 2 * halo;
+        const int64_t per_block = (int64_t)kXSNiter * stride;
+        dim3 grid((unsigned)((a.nx + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, kXSK>),
+                           grid, dim3(64, kXSRows), 0, ctx->stream, a, kXSNiter);
+        return check_launch("sweep_x_dpp");
+    }
     if (axis == ARMON_AXIS_Y) {
         dim3 grid((unsigned)((a.nx + kYBlock - 1) / kYBlock), (unsigned)((a.ny + a.seg - 1) / a.seg));
         hipLaunchKernelGGL(k_sweep_y<PIPE>, grid, dim3(kYBlock), 0, ctx->stream, a);
@@ -352,7 +460,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis)
     }
     dim3 grid((unsigned)((a.nx + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
     const auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool vec_ok = !a.emit && (a.row_len % 2 == 0) && aligned16(a.rho_in) && aligned16(a.ua_in) &&
+    const bool vec_ok = a.x_kernel == 1 && !a.emit && (a.row_len % 2 == 0) && aligned16(a.rho_in) && aligned16(a.ua_in) &&
                         aligned16(a.ut_in) && aligned16(a.E_in) && aligned16(a.rho_out) && aligned16(a.ua_out) &&
                         aligned16(a.ut_out) && aligned16(a.E_out);
     if (vec_ok) {
@@ -438,6 +546,7 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     a.p_out = d->p_out;
     a.c_out = d->c_out;
     a.seg = X ? 512 : 128;
+    a.x_kernel = d->reserved;      // tuning/testing knob: 0 = default (spatial)
 
     if (d->scheme == ARMON_SCHEME_GODUNOV)
         return dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact);

@@ -243,6 +243,29 @@ __device__ __forceinline__ double minmod(double a, double b)
     return __builtin_fmax(0., __builtin_fmin(a, b)) + __builtin_fmin(0., __builtin_fmax(a, b));
 }
 
+// ref src/kernels.jl:16-55 with the four divisions by (1 - s·x) and the two by ρ shared
+__device__ __forceinline__ void bizarrium(double rho, double ua, double ut, double E, double& p, double& cs)
+{
+    const double rho0 = 10000., K0 = 1e+11, Cv0 = 1000., T0 = 300., eps0 = 0., G0 = 1.5, s_ = 1.5;
+    const double q = -42080895. / 14941154., rr = 727668333. / 149411540.;
+    const double inv_rho = rcp(rho);
+    const double x = rho * (1. / rho0) - 1.;
+    const double G = G0 * (1. - rho0 * inv_rho);
+    const double x2 = x * x, x3 = x2 * x;
+    const double opx = 1. + x, opx2 = opx * opx, opx3 = opx2 * opx;
+    const double inv_d = rcp(1. - s_ * x);
+    const double f0 = (1. + (s_ / 3. - 2.) * x + q * x2 + rr * x3) * inv_d;
+    const double f1 = (s_ / 3. - 2. + 2. * q * x + 3. * rr * x2 + s_ * f0) * inv_d;
+    const double f2 = (2. * q + 6. * rr * x + 2. * s_ * f1) * inv_d;
+    const double epsk0 = eps0 - Cv0 * T0 * (1. + G) + 0.5 * (K0 / rho0) * x2 * f0;
+    const double pk0 = -Cv0 * T0 * G0 * rho0 + 0.5 * K0 * x * opx2 * (2. * f0 + x * f1);
+    const double pk0prime = -0.5 * K0 * opx3 * rho0 *
+                            (2. * (1. + 3. * x) * f0 + 2. * x * (2. + 3. * x) * f1 + x2 * opx * f2);
+    const double e = fma_(-0.5, fma_(ua, ua, ut * ut), E);
+    p = pk0 + G0 * rho0 * (e - epsk0);
+    cs = sqrt_(G0 * rho0 * (p - pk0) - pk0prime) * inv_rho;
+}
+
 }  // namespace fast
 
 template <int SCHEME, int LIM, int PROJ, int EOS>
@@ -292,7 +315,7 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         // ---- EOS
         double p, cs;
         if (EOS == ARMON_EOS_BIZARRIUM) {
-            bizarrium_fast(rho, ua, ut, E, p, cs);
+            fast::bizarrium(rho, ua, ut, E, p, cs);
         } else {
             // p = (γ-1)ρe, c = sqrt(γp/ρ) = sqrt(γ(γ-1)e): no division
             const double e = fma_(-0.5, fma_(ua, ua, ut * ut), E);
@@ -418,29 +441,6 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         return o;
     }
 
-    // ref src/kernels.jl:16-55 with the four divisions by (1 - s·x) and the two by ρ shared
-    __device__ __forceinline__ void bizarrium_fast(double rho, double ua, double ut, double E, double& p, double& cs) const
-    {
-        using namespace fast;
-        const double rho0 = 10000., K0 = 1e+11, Cv0 = 1000., T0 = 300., eps0 = 0., G0 = 1.5, s_ = 1.5;
-        const double q = -42080895. / 14941154., rr = 727668333. / 149411540.;
-        const double inv_rho = rcp(rho);
-        const double x = rho * (1. / rho0) - 1.;
-        const double G = G0 * (1. - rho0 * inv_rho);
-        const double x2 = x * x, x3 = x2 * x;
-        const double opx = 1. + x, opx2 = opx * opx, opx3 = opx2 * opx;
-        const double inv_d = rcp(1. - s_ * x);
-        const double f0 = (1. + (s_ / 3. - 2.) * x + q * x2 + rr * x3) * inv_d;
-        const double f1 = (s_ / 3. - 2. + 2. * q * x + 3. * rr * x2 + s_ * f0) * inv_d;
-        const double f2 = (2. * q + 6. * rr * x + 2. * s_ * f1) * inv_d;
-        const double epsk0 = eps0 - Cv0 * T0 * (1. + G) + 0.5 * (K0 / rho0) * x2 * f0;
-        const double pk0 = -Cv0 * T0 * G0 * rho0 + 0.5 * K0 * x * opx2 * (2. * f0 + x * f1);
-        const double pk0prime = -0.5 * K0 * opx3 * rho0 *
-                                (2. * (1. + 3. * x) * f0 + 2. * x * (2. + 3. * x) * f1 + x2 * opx * f2);
-        const double e = fma_(-0.5, fma_(ua, ua, ut * ut), E);
-        p = pk0 + G0 * rho0 * (e - epsk0);
-        cs = sqrt_(G0 * rho0 * (p - pk0) - pk0prime) * inv_rho;
-    }
 };
 
 }  // namespace fused

@@ -207,7 +207,8 @@ typedef struct {
     int32_t bc_low, bc_high; /* 1: physical boundary on the low/high side of `axis` → mirror BC
                                 applied in-tile; 0: ghosts already hold neighbour data (halo)   */
     int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to staged  */
-    int32_t reserved;
+    int32_t reserved;        /* X-sweep kernel form, for tests/tuning: 0 default (lanes along x, DPP
+                                shifts), 1 LDS-transposed march with 16-B accesses, 2 generic LDS march */
     int64_t nx, ny;          /* real cells of the block                                         */
     double  dt, dx;          /* sweep time step (current_dt·factor) and cell size along axis    */
     double  gamma;           /* perfect gas only                                                */
