@@ -46,14 +46,15 @@ class SweepDesc(C.Structure):
     _fields_ = [("axis", C.c_int32), ("scheme", C.c_int32), ("limiter", C.c_int32),
                 ("projection", C.c_int32), ("eos", C.c_int32), ("nghost", C.c_int32),
                 ("bc_low", C.c_int32), ("bc_high", C.c_int32), ("exact", C.c_int32),
-                ("reserved", C.c_int32),
+                ("x_kernel", C.c_int32),
                 ("nx", C.c_int64), ("ny", C.c_int64),
                 ("dt", C.c_double), ("dx", C.c_double), ("gamma", C.c_double),
                 ("u_factor_low", C.c_double), ("v_factor_low", C.c_double),
                 ("u_factor_high", C.c_double), ("v_factor_high", C.c_double),
                 ("rho_in", C.c_void_p), ("u_in", C.c_void_p), ("v_in", C.c_void_p), ("E_in", C.c_void_p),
                 ("rho_out", C.c_void_p), ("u_out", C.c_void_p), ("v_out", C.c_void_p), ("E_out", C.c_void_p),
-                ("p_out", C.c_void_p), ("c_out", C.c_void_p)]
+                ("p_out", C.c_void_p), ("c_out", C.c_void_p),
+                ("dt_cfl_out", C.c_void_p), ("cfl_dx", C.c_double), ("cfl_dy", C.c_double)]
 
 
 _lib = None

@@ -16,7 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # CPU oracle); the tuned kernels ask for FMAs explicitly.
 CXXFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
             "-Wall", "-Wextra", "-Wno-unused-parameter", "-fvisibility=hidden",
-            "-DARMON_BUILDING_LIB"]
+            "-DARMON_BUILDING_LIB"] + os.environ.get("ARMON_EXTRA_FLAGS", "").split()
 
 
 def sources():

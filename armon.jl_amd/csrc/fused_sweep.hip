@@ -1,20 +1,25 @@
 // fused_sweep.hip — armon_hip_sweep: one directional sweep of solver_cycle (ref src/solver.jl:300-316)
 // as ONE kernel launch: EOS → boundary mirror → fluxes → cell update → advection → projection, reading
-// ρ,u,v,E once and writing them once (64 B per cell instead of the 352 B of the five staged passes).
+// ρ,u,v,E once and writing them once (64 B per cell instead of the 352 B of the five staged passes),
+// optionally followed by the dt/CFL reduction of the next cycle (ref src/reductions.jl:2-53) on the state
+// it has just produced.
 //
-// Both kernels run the register pipeline of sweep_pipeline.hpp; they differ only in how a lane gets the
-// cells it marches over:
-//  * Y sweep: lane ↔ column. Rows are x-contiguous, so every step of the march is one fully coalesced
-//    row segment per wave; no LDS at all. A workgroup owns 256 columns × one run of rows.
-//  * X sweep: the march runs along the contiguous axis, so lane ↔ row and the wave transposes through
-//    LDS: a 64-row × CH-column tile is loaded with coalesced row segments, each lane walks its row in
-//    LDS (odd row pitch → conflict-free column reads), writes the results back in place, and the tile
-//    is stored with coalesced row segments again. One wave per workgroup, so the barriers are free.
-// Redundant work is confined to the LAG (≤4) cells at both ends of a run.
+// Kernels:
+//  * Y sweep (k_sweep_y): lane ↔ column, the register pipeline of sweep_pipeline.hpp marches along y.
+//    Rows are x-contiguous, so every step is one fully coalesced row segment per wave; no LDS. A
+//    workgroup owns 256 columns × one run of rows; 4 rows per lane are kept in flight.
+//  * X sweep, spatial form (k_sweep_x_dpp, default): lane ↔ cell(s) of a row, neighbours fetched with
+//    DPP wavefront shifts (sweep_spatial.hpp); no LDS, no barrier, coalesced 16-B accesses.
+//  * X sweep, LDS-transposed march (k_sweep_x_lds, alternative form kept for A/B measurements): a wave
+//    transposes 64-row × 8-column tiles through LDS and each lane marches along its row with the same
+//    pipeline as the Y sweep.
+// Redundant work is confined to the LAG (≤4) cells at both ends of a run / strip.
 #include "common.hpp"
+#include "reduce.hpp"
 #include "sweep_pipeline.hpp"
 #include "sweep_spatial.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -27,13 +32,14 @@ struct sweep_args {
     int32_t g;                     // ghost layers
     int32_t bc_low, bc_high;       // mirror BC applied in-kernel on that side of the sweep axis
     int32_t emit;                  // bit 0: write p_out, bit 1: write c_out
-    int64_t seg;                   // cells per run along the sweep axis
-    int32_t x_kernel;              // X sweep form: 0 spatial (DPP), 1 LDS-transposed march (vector), 2 generic march
+    int32_t seg;                   // cells per run along the sweep axis (marching kernels)
+    int32_t x_kernel;              // X sweep form: 0 spatial K=2, 3 spatial K=1, 2 LDS-transposed march
     double dt, dx, gamma;
     double fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const double *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
     double *rho_out, *ua_out, *ut_out, *E_out;
     double *p_out, *c_out;
+    double* partials;              // dt/CFL tracking: [2 * n_blocks] (max |u|±c, max |v|±c per workgroup)
 };
 
 // Source index and velocity factors of cell `j` (0-based real coordinate along the sweep axis, may be
@@ -62,169 +68,192 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&
     (f(std::integral_constant<int, Is>{}), ...);
 }
 
+// Buffer addressing (T8): 128-bit resource descriptor in SGPRs + 32-bit lane offset + 32-bit scalar
+// row offset. No per-access 64-bit VALU address arithmetic; advancing a row is one s_add_u32.
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ double buf_load(rsrc_t r, unsigned voff, unsigned soff)
+{
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __builtin_bit_cast(double, v);
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff, double x)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, soff, 0);
+}
+
+// dt/CFL tracking (ref src/reductions.jl:13-20). The reference takes min over cells of
+// min(dx/|max(|u+c|,|u-c|)|, dy/|max(|v+c|,|v-c|)|); IEEE division is monotonic, so that minimum equals
+// min(dx / max_cells(..u..), dy / max_cells(..v..)) bit for bit: track the two maxima, divide once.
+struct cfl_track {
+    double au = 0., av = 0.;
+    __device__ __forceinline__ void add(double u, double v, double c)
+    {
+        au = phys::mx(au, fabs(phys::mx(fabs(u + c), fabs(u - c))));
+        av = phys::mx(av, fabs(phys::mx(fabs(v + c), fabs(v - c))));
+    }
+};
+
+template <int NWAVES>
+__device__ __forceinline__ void cfl_block_store(const cfl_track& t, double* partials, int64_t block, int tid)
+{
+    __shared__ double lds[NWAVES];
+    const double au = red::block_reduce<red::op_max, NWAVES>(t.au, lds, tid);
+    const double av = red::block_reduce<red::op_max, NWAVES>(t.av, lds, tid);
+    if (tid == 0) {
+        partials[2 * block] = au;
+        partials[2 * block + 1] = av;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_fold_dt(const double* __restrict__ partials, int64_t n_blocks, double dx, double dy, double* __restrict__ out)
+{
+    __shared__ double lds[4];
+    double au = 0., av = 0.;
+    for (int64_t k = threadIdx.x; k < n_blocks; k += blockDim.x) {
+        au = phys::mx(au, partials[2 * k]);
+        av = phys::mx(av, partials[2 * k + 1]);
+    }
+    au = red::block_reduce<red::op_max, 4>(au, lds, threadIdx.x);
+    av = red::block_reduce<red::op_max, 4>(av, lds, threadIdx.x);
+    if (threadIdx.x == 0) out[0] = phys::mn(dx / au, dy / av);
+}
+
 // ---- Y sweep ---------------------------------------------------------------------------------------
 constexpr int kYBlock = 256;
+#ifndef ARMON_Y_WAVES
+#define ARMON_Y_WAVES 2          // minimum waves per SIMD the Y march is compiled for (register budget)
+#endif
 
-template <class PIPE>
-__global__ void __launch_bounds__(kYBlock)
+template <class PIPE, bool TRACK>
+__global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
 k_sweep_y(sweep_args a)
 {
     constexpr int LAG = PIPE::LAG;
     constexpr int PF = 4;            // rows in flight per lane (= the unroll of the march)
-    const int64_t x = (int64_t)blockIdx.x * kYBlock + threadIdx.x;
-    if (x >= a.nx) return;
-    const int64_t o0 = (int64_t)blockIdx.y * a.seg;
-    const int64_t o1 = (o0 + a.seg < a.ny) ? o0 + a.seg : a.ny;
-    const unsigned col = (unsigned)(x + a.g);    // 32-bit lane offset; row bases stay scalar
+    const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
+    const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x);
+    const bool active = xr < nx;
+    const int x = active ? xr : nx - 1;          // idle lanes shadow the last column and never store
+    const int o0 = (int)blockIdx.y * a.seg;
+    const int o1 = (o0 + a.seg < ny) ? o0 + a.seg : ny;
+    const int jb = o0 - LAG, je = o1 + LAG;
+
+    // Descriptors are based at the first row this run touches, so every scalar row offset is a small
+    // non-negative 32-bit number whatever the size of the arrays (mirrored rows lie inside the run).
+    const unsigned colb = (unsigned)(x + g) * 8u;
+    const unsigned pitchb = (unsigned)a.row_len * 8u;
+    const int64_t in_base = (int64_t)(jb + g) * a.row_len, out_base = (int64_t)(o0 + g) * a.row_len;
+    const rsrc_t r_rho = make_rsrc(a.rho_in + in_base), r_ua = make_rsrc(a.ua_in + in_base);
+    const rsrc_t r_ut = make_rsrc(a.ut_in + in_base), r_E = make_rsrc(a.E_in + in_base);
+    const rsrc_t w_rho = make_rsrc(a.rho_out + out_base), w_ua = make_rsrc(a.ua_out + out_base);
+    const rsrc_t w_ut = make_rsrc(a.ut_out + out_base), w_E = make_rsrc(a.E_out + out_base);
 
     PIPE pipe(a.dt, a.dx, a.gamma);
+    cfl_track cfl;
 
-    const int64_t j_begin = o0 - LAG, j_end = o1 + LAG;
     double pr[PF][4];                // prefetch ring: (ρ, ua, ut, E) of rows j .. j+PF-1
-    // Loads one row of this lane's column (clamped to the run so that padding steps stay in bounds).
-    auto load = [&](auto slot, int64_t j) {
+    int lj = jb;                     // next row to load and its offset from the run's first row
+    unsigned lo_off = 0;
+    unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;     // row j - LAG relative to row o0 (wraps until valid)
+
+    // CHECKED steps handle everything (mirrored / clamped loads, masked stores, p/c output); the steady
+    // state of a run uses the unchecked form: plain loads, unconditional stores, one basic block.
+    auto load = [&](auto slot, auto checked) {
         constexpr int K = decltype(slot)::value;
-        double fa, ft;
-        const int64_t jc = j < j_end ? j : j_end - 1;
-        const int64_t row = (bc_source(a, a.ny, jc, fa, ft) + a.g) * a.row_len;   // uniform
-        pr[K][0] = (a.rho_in + row)[col];
-        pr[K][1] = (a.ua_in + row)[col] * fa;
-        pr[K][2] = (a.ut_in + row)[col] * ft;
-        pr[K][3] = (a.E_in + row)[col];
+        constexpr bool CHECKED = decltype(checked)::value;
+        if (CHECKED) {
+            const bool m_lo = lj < 0 && a.bc_low, m_hi = lj >= ny && a.bc_high;     // uniform, rare
+            // physical boundary: mirror of the inside (ref src/halo_exchange.jl:2-29)
+            const int src = m_lo ? -1 - lj : (m_hi ? 2 * ny - 1 - lj : lj);
+            const unsigned off = (unsigned)(src - jb) * pitchb;
+            const double fa = m_lo ? a.fa_low : (m_hi ? a.fa_high : 1.);
+            const double ft = m_lo ? a.ft_low : (m_hi ? a.ft_high : 1.);
+            pr[K][0] = buf_load(r_rho, colb, off);
+            pr[K][1] = buf_load(r_ua, colb, off) * fa;
+            pr[K][2] = buf_load(r_ut, colb, off) * ft;
+            pr[K][3] = buf_load(r_E, colb, off);
+            if (lj + 1 < je) {       // stay on the last row once the run is exhausted (padding steps)
+                lj++;
+                lo_off += pitchb;
+            }
+        } else {
+            pr[K][0] = buf_load(r_rho, colb, lo_off);
+            pr[K][1] = buf_load(r_ua, colb, lo_off);
+            pr[K][2] = buf_load(r_ut, colb, lo_off);
+            pr[K][3] = buf_load(r_E, colb, lo_off);
+            lj++;
+            lo_off += pitchb;
+        }
     };
-    auto step = [&](auto ph, int64_t j) {
+    auto step = [&](auto ph, auto checked, int j) {
         constexpr int PH = decltype(ph)::value;
+        constexpr bool CHECKED = decltype(checked)::value;
         const double rho = pr[PH][0], ua = pr[PH][1], ut = pr[PH][2], E = pr[PH][3];
-        load(ph, j + PF);            // refill this slot: PF rows ahead of the march
-        double p, c;
-        const fused::Out4 out = pipe.template push<true, PH>(rho, ua, ut, E, p, c);
-        if (a.emit && j >= o0 && j < o1) {
-            const int64_t row = (j + a.g) * a.row_len;
-            if (a.emit & 1) (a.p_out + row)[col] = p;
-            if (a.emit & 2) (a.c_out + row)[col] = c;
+        load(ph, checked);           // refill this slot: PF rows ahead of the march
+        double p, c, c_lag;
+        const fused::Out4 out = pipe.template push<true, PH>(rho, ua, ut, E, p, c, c_lag);
+        const int o = j - LAG;
+        if (CHECKED) {
+            if (a.emit && j >= o0 && j < o1 && active) {
+                const unsigned off = so_off + LAG * pitchb;
+                if (a.emit & 1) buf_store(make_rsrc(a.p_out + out_base), colb, off, p);
+                if (a.emit & 2) buf_store(make_rsrc(a.c_out + out_base), colb, off, c);
+            }
         }
-        const int64_t o = j - LAG;
-        if (o >= o0 && o < o1) {
-            const int64_t row = (o + a.g) * a.row_len;
-            (a.rho_out + row)[col] = out.rho;
-            (a.ua_out + row)[col] = out.ua;
-            (a.ut_out + row)[col] = out.ut;
-            (a.E_out + row)[col] = out.E;
+        if (!CHECKED || (o >= o0 && o < o1)) {
+            if (active) {
+                buf_store(w_rho, colb, so_off, out.rho);
+                buf_store(w_ua, colb, so_off, out.ua);
+                buf_store(w_ut, colb, so_off, out.ut);
+                buf_store(w_E, colb, so_off, out.E);
+            }
+            if (TRACK) cfl.add(out.ut, out.ua, c_lag);      // Y sweep: ut = u, ua = v
+        }
+        so_off += pitchb;
+    };
+    using std::integral_constant;
+    auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 4
+        for (int t = t0; t < t1; t += 4) {
+            step(integral_constant<int, 0>{}, checked, jb + t);
+            step(integral_constant<int, 1>{}, checked, jb + t + 1);
+            step(integral_constant<int, 2>{}, checked, jb + t + 2);
+            step(integral_constant<int, 3>{}, checked, jb + t + 3);
         }
     };
 
-    load(std::integral_constant<int, 0>{}, j_begin);
-    load(std::integral_constant<int, 1>{}, j_begin + 1);
-    load(std::integral_constant<int, 2>{}, j_begin + 2);
-    load(std::integral_constant<int, 3>{}, j_begin + 3);
-    // The march is unrolled by the 4 phases of the pipeline's history rings.
-    for (int64_t j = j_begin; j < j_end; j += 4) {
-        step(std::integral_constant<int, 0>{}, j);
-        step(std::integral_constant<int, 1>{}, j + 1);
-        step(std::integral_constant<int, 2>{}, j + 2);
-        step(std::integral_constant<int, 3>{}, j + 3);
-    }
-}
+    const int T = je - jb;                                   // steps of the run
+    const int T4 = (T + 3) & ~3;                             // … padded to the unroll
+    const int P = (2 * LAG + 3) & ~3;                        // after P steps every step emits a valid cell
+    // last step (exclusive) whose prefetch needs neither mirroring nor clamping and whose store is valid
+    const int plain_end = (a.bc_high && ny < je ? ny : je) - jb - PF;
+    int M = (T < plain_end ? T : plain_end) & ~3;
+    if (M < P || (a.emit & 3)) M = P;                        // p/c output: everything through the checked form
 
-// ---- X sweep ---------------------------------------------------------------------------------------
-constexpr int kXRows = 64;      // one wave: lane ↔ row
+    load(integral_constant<int, 0>{}, std::true_type{});
+    load(integral_constant<int, 1>{}, std::true_type{});
+    load(integral_constant<int, 2>{}, std::true_type{});
+    load(integral_constant<int, 3>{}, std::true_type{});
+    run(std::true_type{}, 0, P < T4 ? P : T4);
+    run(std::false_type{}, P, M);
+    run(std::true_type{}, M, T4);
 
-template <class PIPE, int CH>
-__global__ void __launch_bounds__(kXRows, 2)
-k_sweep_x(sweep_args a)
-{
-    constexpr int LAG = PIPE::LAG;
-    constexpr int PITCH = CH + 1;                 // odd pitch in doubles: conflict-free column walks
-    constexpr int RPI = kXRows / CH;              // rows covered by one wave-wide row-segment access
-    extern __shared__ double tile[];              // [planes][64][PITCH], planes = 4 (+2 when emitting p, c)
-
-    const int lane = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.y * kXRows;
-    const int64_t o0 = (int64_t)blockIdx.x * a.seg;
-    const int64_t o1 = (o0 + a.seg < a.nx) ? o0 + a.seg : a.nx;
-    const int64_t j_end = o1 + LAG;
-    const bool row_ok = (r0 + lane) < a.ny;
-    const bool emit = a.emit != 0;
-
-    const int sub_row = lane / CH, sub_col = lane % CH;   // row-segment phase: lane → (row in group, column)
-    auto T = [&](int plane, int r, int t) -> double& { return tile[(plane * kXRows + r) * PITCH + t]; };
-
-    PIPE pipe(a.dt, a.dx, a.gamma);
-
-    for (int64_t jb = o0 - LAG; jb < j_end; jb += CH) {
-        // -- load phase: 64 rows × CH columns, 8 B per lane, CH*8 B contiguous per row
-        {
-            const int64_t j = jb + sub_col;
-            double fa, ft;
-            const int64_t src = bc_source(a, a.nx, j, fa, ft);
-#pragma unroll
-            for (int k = 0; k < CH; k++) {
-                const int r = k * RPI + sub_row;
-                const int64_t row = r0 + r;
-                if (row < a.ny && j < j_end) {
-                    const int64_t idx = (row + a.g) * a.row_len + (src + a.g);
-                    T(0, r, sub_col) = a.rho_in[idx];
-                    T(1, r, sub_col) = a.ua_in[idx] * fa;
-                    T(2, r, sub_col) = a.ut_in[idx] * ft;
-                    T(3, r, sub_col) = a.E_in[idx];
-                }
-            }
-        }
-        __syncthreads();
-        // -- march: lane walks its own row through the tile, results overwrite the consumed slots
-        if (row_ok) {
-            static_for(std::make_integer_sequence<int, CH>{}, [&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                const int64_t j = jb + t;
-                if (j < j_end) {
-                    double p, c;
-                    const fused::Out4 out = pipe.template push<false, (t & 3)>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c);
-                    T(0, lane, t) = out.rho;
-                    T(1, lane, t) = out.ua;
-                    T(2, lane, t) = out.ut;
-                    T(3, lane, t) = out.E;
-                    if (emit) {
-                        T(4, lane, t) = p;
-                        T(5, lane, t) = c;
-                    }
-                }
-            });
-        }
-        __syncthreads();
-        // -- store phase: slot t holds the new state of column jb + t - LAG (and p, c of column jb + t)
-        {
-            const int64_t j = jb + sub_col;
-            const int64_t o = j - LAG;
-#pragma unroll
-            for (int k = 0; k < CH; k++) {
-                const int r = k * RPI + sub_row;
-                const int64_t row = r0 + r;
-                if (row < a.ny && j < j_end) {
-                    if (o >= o0) {
-                        const int64_t io = (row + a.g) * a.row_len + (o + a.g);
-                        a.rho_out[io] = T(0, r, sub_col);
-                        a.ua_out[io] = T(1, r, sub_col);
-                        a.ut_out[io] = T(2, r, sub_col);
-                        a.E_out[io] = T(3, r, sub_col);
-                    }
-                    if (emit && j >= o0 && j < o1) {
-                        const int64_t ij = (row + a.g) * a.row_len + (j + a.g);
-                        if (a.emit & 1) a.p_out[ij] = T(4, r, sub_col);
-                        if (a.emit & 2) a.c_out[ij] = T(5, r, sub_col);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+    if (TRACK) cfl_block_store<kYBlock / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
 
 // ---- X sweep, spatial form (lanes along x, DPP neighbour exchange) -------------------------------------
 // blockDim = (64, kXSRows): one wave per row, kXSRows consecutive rows per workgroup. Each wave walks
 // NITER strips of 64*K cells along its row; a strip yields 64*K - 2*HALO new cells.
 constexpr int kXSRows = 4;
+constexpr int kXSNiter = 8;      // strips per wave
 
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K>
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
 __global__ void __launch_bounds__(64 * kXSRows)
 k_sweep_x_dpp(sweep_args a, int niter)
 {
@@ -236,17 +265,19 @@ k_sweep_x_dpp(sweep_args a, int niter)
     constexpr int STRIDE = WIDTH - 2 * HALO;
 
     const int lane = threadIdx.x;
-    const int64_t row = (int64_t)blockIdx.y * kXSRows + threadIdx.y;
-    if (row >= a.ny) return;                       // whole wave
+    const int64_t row_r = (int64_t)blockIdx.y * kXSRows + threadIdx.y;
+    const bool row_ok = row_r < a.ny;                         // whole wave
+    const int64_t row = row_ok ? row_r : a.ny - 1;
     const int64_t row_off = (row + a.g) * a.row_len + a.g;
     const double* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
     double* out[4] = {a.rho_out + row_off, a.ua_out + row_off, a.ut_out + row_off, a.E_out + row_off};
     const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && (a.g % 2 == 0);   // uniform
 
     SW sw{a.dt, a.dx, a.gamma};
+    cfl_track cfl;
 
     const int64_t w_first = (int64_t)blockIdx.x * niter * STRIDE;
-    for (int it = 0; it < niter; it++) {
+    for (int it = 0; it < niter && row_ok; it++) {
         const int64_t w0 = w_first + (int64_t)it * STRIDE;    // first cell this strip produces
         if (w0 >= a.nx) break;
         const int64_t cb = w0 - HALO;                         // first cell of the strip
@@ -296,6 +327,10 @@ k_sweep_x_dpp(sweep_args a, int niter)
                 if (a.emit & 1) *reinterpret_cast<double2*>(a.p_out + row_off + j0) = double2{p.v[0], p.v[K - 1]};
                 if (a.emit & 2) *reinterpret_cast<double2*>(a.c_out + row_off + j0) = double2{cs.v[0], cs.v[K - 1]};
             }
+            if (TRACK) {
+                cfl.add(o_u.v[0], o_v.v[0], cs.v[0]);
+                cfl.add(o_u.v[K - 1], o_v.v[K - 1], cs.v[K - 1]);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < K; k++) {
@@ -307,85 +342,63 @@ k_sweep_x_dpp(sweep_args a, int niter)
                     out[3][j] = o_E.v[k];
                     if (a.emit & 1) (a.p_out + row_off)[j] = p.v[k];
                     if (a.emit & 2) (a.c_out + row_off)[j] = cs.v[k];
+                    if (TRACK) cfl.add(o_u.v[k], o_v.v[k], cs.v[k]);
                 }
             }
         }
     }
+    if (TRACK)
+        cfl_block_store<kXSRows>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x,
+                                 threadIdx.y * 64 + threadIdx.x);
 }
 
-// Vectorised X sweep for even row pitch (16-B aligned column pairs): CH = 16 columns per chunk = one
-// 128-B line per row and array, 16-B loads/stores, and the NEXT chunk's 32 loads are issued into registers
-// before the march over the current chunk starts, so a single wave per SIMD keeps ~32 KB in flight.
-constexpr int kXVecChunk = 16;
+// ---- X sweep, LDS-transposed march (alternative form) -----------------------------------------------------
+constexpr int kXRows = 64;      // one wave: lane ↔ row
+constexpr int kXChunk = 8;
 
-template <class PIPE, int CH>
-__global__ void __launch_bounds__(kXRows, 1)
-k_sweep_x_vec(sweep_args a)
+template <class PIPE, int CH, bool TRACK>
+__global__ void __launch_bounds__(kXRows, 2)
+k_sweep_x_lds(sweep_args a)
 {
     constexpr int LAG = PIPE::LAG;
-    constexpr int PITCH = CH + 2;                 // even pitch: 16-B aligned pairs for the row phases
-    constexpr int LPR = CH / 2;                   // lanes per row in the row phases (16 B each)
-    constexpr int RPI = kXRows / LPR;             // rows per wave-wide access
-    constexpr int NI = kXRows / RPI;              // accesses per array and chunk
-    constexpr bool VEC_STORE = (LAG % 2) == 0;    // output column pairs are 16-B aligned only for even LAG
-    __shared__ double2 tile2[4 * kXRows * PITCH / 2];
-    double* tile = reinterpret_cast<double*>(tile2);
+    constexpr int PITCH = CH + 1;                 // odd pitch in doubles: conflict-free column walks
+    constexpr int RPI = kXRows / CH;              // rows covered by one wave-wide row-segment access
+    extern __shared__ double tile[];              // [planes][64][PITCH], planes = 4 (+2 when emitting p, c)
 
     const int lane = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * kXRows;
     const int64_t o0 = (int64_t)blockIdx.x * a.seg;
     const int64_t o1 = (o0 + a.seg < a.nx) ? o0 + a.seg : a.nx;
-    const int64_t j_begin = o0 - LAG - ((a.g - LAG) & 1);   // (j_begin + g) even → aligned pairs
     const int64_t j_end = o1 + LAG;
     const bool row_ok = (r0 + lane) < a.ny;
-    const int sub_row = lane / LPR, sub_pair = lane % LPR;
-    const double* in[4] = {a.rho_in, a.ua_in, a.ut_in, a.E_in};
-    double* out[4] = {a.rho_out, a.ua_out, a.ut_out, a.E_out};
+    const bool emit = a.emit != 0;
 
+    const int sub_row = lane / CH, sub_col = lane % CH;   // row-segment phase: lane → (row in group, column)
     auto T = [&](int plane, int r, int t) -> double& { return tile[(plane * kXRows + r) * PITCH + t]; };
 
     PIPE pipe(a.dt, a.dx, a.gamma);
-    double2 R[4][NI];
+    cfl_track cfl;
 
-    // One element with boundary handling (edge chunks only).
-    auto elem = [&](int f, int64_t row, int64_t j) -> double {
-        double fa, ft;
-        const int64_t jc = j < j_end ? j : j_end - 1;
-        const int64_t src = bc_source(a, a.nx, jc, fa, ft);
-        const double v = in[f][(row + a.g) * a.row_len + (src + a.g)];
-        return f == 1 ? v * fa : (f == 2 ? v * ft : v);
-    };
-    auto load_chunk = [&](int64_t jb) {
-        const int64_t j = jb + 2 * sub_pair;
-        const bool interior = jb >= 0 && jb + CH <= a.nx;      // uniform
+    for (int64_t jb = o0 - LAG; jb < j_end; jb += CH) {
+        // -- load phase: 64 rows × CH columns, 8 B per lane, CH*8 B contiguous per row
+        {
+            const int64_t j = jb + sub_col;
+            double fa, ft;
+            const int64_t src = bc_source(a, a.nx, j, fa, ft);
 #pragma unroll
-        for (int k = 0; k < NI; k++) {
-            const int64_t row = r0 + k * RPI + sub_row;
-            if (row < a.ny) {
-                if (interior) {
-                    const int64_t idx = (row + a.g) * a.row_len + (j + a.g);
-#pragma unroll
-                    for (int f = 0; f < 4; f++) R[f][k] = *reinterpret_cast<const double2*>(in[f] + idx);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < 4; f++) R[f][k] = double2{elem(f, row, j), elem(f, row, j + 1)};
+            for (int k = 0; k < CH; k++) {
+                const int r = k * RPI + sub_row;
+                const int64_t row = r0 + r;
+                if (row < a.ny && j < j_end) {
+                    const int64_t idx = (row + a.g) * a.row_len + (src + a.g);
+                    T(0, r, sub_col) = a.rho_in[idx];
+                    T(1, r, sub_col) = a.ua_in[idx] * fa;
+                    T(2, r, sub_col) = a.ut_in[idx] * ft;
+                    T(3, r, sub_col) = a.E_in[idx];
                 }
             }
         }
-    };
-
-    load_chunk(j_begin);
-    for (int64_t jb = j_begin; jb < j_end; jb += CH) {
-        // -- registers → LDS tile
-#pragma unroll
-        for (int k = 0; k < NI; k++) {
-            const int r = k * RPI + sub_row;
-#pragma unroll
-            for (int f = 0; f < 4; f++) *reinterpret_cast<double2*>(&T(f, r, 2 * sub_pair)) = R[f][k];
-        }
         __syncthreads();
-        // -- prefetch the next chunk while this one is marched over
-        if (jb + CH < j_end) load_chunk(jb + CH);
         // -- march: lane walks its own row through the tile, results overwrite the consumed slots
         if (row_ok) {
 #pragma unroll 1
@@ -393,106 +406,124 @@ k_sweep_x_vec(sweep_args a)
                 static_for(std::make_integer_sequence<int, 4>{}, [&](auto phc) {
                     constexpr int PH = decltype(phc)::value;
                     const int t = t0 + PH;
-                    if (jb + t < j_end) {
-                        double p, c;
-                        const fused::Out4 o = pipe.template push<false, PH>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c);
-                        T(0, lane, t) = o.rho;
-                        T(1, lane, t) = o.ua;
-                        T(2, lane, t) = o.ut;
-                        T(3, lane, t) = o.E;
+                    const int64_t j = jb + t;
+                    if (j < j_end) {
+                        double p, c, c_lag;
+                        const fused::Out4 out = pipe.template push<false, PH>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c, c_lag);
+                        T(0, lane, t) = out.rho;
+                        T(1, lane, t) = out.ua;
+                        T(2, lane, t) = out.ut;
+                        T(3, lane, t) = out.E;
+                        if (emit) {
+                            T(4, lane, t) = p;
+                            T(5, lane, t) = c;
+                        }
+                        if (TRACK && j - LAG >= o0) cfl.add(out.ua, out.ut, c_lag);
                     }
                 });
             }
         }
         __syncthreads();
-        // -- store phase: slot t holds the new state of column jb + t - LAG
+        // -- store phase: slot t holds the new state of column jb + t - LAG (and p, c of column jb + t)
         {
-            const int64_t o = jb + 2 * sub_pair - LAG;
-            const bool interior = VEC_STORE && (jb - LAG >= o0) && (jb + CH - LAG <= o1);   // uniform
+            const int64_t j = jb + sub_col;
+            const int64_t o = j - LAG;
 #pragma unroll
-            for (int k = 0; k < NI; k++) {
+            for (int k = 0; k < CH; k++) {
                 const int r = k * RPI + sub_row;
                 const int64_t row = r0 + r;
-                if (row < a.ny) {
-                    const int64_t io = (row + a.g) * a.row_len + (o + a.g);
-                    if (interior) {
-#pragma unroll
-                        for (int f = 0; f < 4; f++)
-                            *reinterpret_cast<double2*>(out[f] + io) = *reinterpret_cast<const double2*>(&T(f, r, 2 * sub_pair));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            const int64_t oe = o + e;
-                            if (oe >= o0 && oe < o1 && jb + 2 * sub_pair + e < j_end) {
-#pragma unroll
-                                for (int f = 0; f < 4; f++) out[f][io + e] = T(f, r, 2 * sub_pair + e);
-                            }
-                        }
+                if (row < a.ny && j < j_end) {
+                    if (o >= o0) {
+                        const int64_t io = (row + a.g) * a.row_len + (o + a.g);
+                        a.rho_out[io] = T(0, r, sub_col);
+                        a.ua_out[io] = T(1, r, sub_col);
+                        a.ut_out[io] = T(2, r, sub_col);
+                        a.E_out[io] = T(3, r, sub_col);
+                    }
+                    if (emit && j >= o0 && j < o1) {
+                        const int64_t ij = (row + a.g) * a.row_len + (j + a.g);
+                        if (a.emit & 1) a.p_out[ij] = T(4, r, sub_col);
+                        if (a.emit & 2) a.c_out[ij] = T(5, r, sub_col);
                     }
                 }
             }
         }
         __syncthreads();
     }
+    if (TRACK) cfl_block_store<1>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
 
-constexpr int kXChunk = 8;
-
-constexpr int kXSK = 2;          // cells per lane of the spatial X sweep
-constexpr int kXSNiter = 8;      // strips per wave
-
-template <class PIPE>
-int launch(armon_ctx* ctx, const sweep_args& a, int axis)
+// ---- launch ----------------------------------------------------------------------------------------------
+template <class PIPE, bool TRACK>
+int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
 {
-    if (axis == ARMON_AXIS_X && a.x_kernel == 0) {
-        constexpr int halo = (kXSK == 1) ? PIPE::LAG : ((PIPE::LAG + 1) & ~1);
-        constexpr int stride = 64 * kXSK - 2 * halo;
-        const int64_t per_block = (int64_t)kXSNiter * stride;
-        dim3 grid((unsigned)((a.nx + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
-        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, kXSK>),
-                           grid, dim3(64, kXSRows), 0, ctx->stream, a, kXSNiter);
-        return check_launch("sweep_x_dpp");
-    }
     if (axis == ARMON_AXIS_Y) {
         dim3 grid((unsigned)((a.nx + kYBlock - 1) / kYBlock), (unsigned)((a.ny + a.seg - 1) / a.seg));
-        hipLaunchKernelGGL(k_sweep_y<PIPE>, grid, dim3(kYBlock), 0, ctx->stream, a);
+        *n_blocks = (int64_t)grid.x * grid.y;
+        hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
         return check_launch("sweep_y");
     }
-    dim3 grid((unsigned)((a.nx + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
-    const auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool vec_ok = a.x_kernel == 1 && !a.emit && (a.row_len % 2 == 0) && aligned16(a.rho_in) && aligned16(a.ua_in) &&
-                        aligned16(a.ut_in) && aligned16(a.E_in) && aligned16(a.rho_out) && aligned16(a.ua_out) &&
-                        aligned16(a.ut_out) && aligned16(a.E_out);
-    if (vec_ok) {
-        hipLaunchKernelGGL((k_sweep_x_vec<PIPE, kXVecChunk>), grid, dim3(kXRows), 0, ctx->stream, a);
-        return check_launch("sweep_x_vec");
+    if (a.x_kernel == 2) {
+        dim3 grid((unsigned)((a.nx + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
+        *n_blocks = (int64_t)grid.x * grid.y;
+        const size_t lds = (size_t)(a.emit ? 6 : 4) * kXRows * (kXChunk + 1) * sizeof(double);
+        hipLaunchKernelGGL((k_sweep_x_lds<PIPE, kXChunk, TRACK>), grid, dim3(kXRows), lds, ctx->stream, a);
+        return check_launch("sweep_x_lds");
     }
-    const size_t lds = (size_t)(a.emit ? 6 : 4) * kXRows * (kXChunk + 1) * sizeof(double);
-    hipLaunchKernelGGL((k_sweep_x<PIPE, kXChunk>), grid, dim3(kXRows), lds, ctx->stream, a);
-    return check_launch("sweep_x");
+    static const int niter_env = getenv("ARMON_XS_NITER") ? atoi(getenv("ARMON_XS_NITER")) : 0;   // tuning knob
+    const int niter = niter_env > 0 ? niter_env : kXSNiter;
+    const bool k1 = a.x_kernel == 3;
+    const int halo = k1 ? PIPE::LAG : ((PIPE::LAG + 1) & ~1);
+    const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
+    dim3 grid((unsigned)((a.nx + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
+    *n_blocks = (int64_t)grid.x * grid.y;
+    if (k1)
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
+                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+    else
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK>),
+                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+    return check_launch("sweep_x_dpp");
+}
+
+// Upper bound of the number of workgroups any form launches for this block (sizes the partials buffer).
+int64_t max_blocks(const sweep_args& a)
+{
+    const int64_t by = (a.nx + kYBlock - 1) / kYBlock * ((a.ny + a.seg - 1) / a.seg);
+    const int64_t bx_lds = (a.nx + a.seg - 1) / a.seg * ((a.ny + kXRows - 1) / kXRows);
+    const int64_t bx_dpp = (a.nx / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows);     // niter >= 1, K = 1, LAG = 4
+    int64_t m = by > bx_lds ? by : bx_lds;
+    return m > bx_dpp ? m : bx_dpp;
+}
+
+template <class PIPE>
+int dispatch_track(armon_ctx* ctx, const sweep_args& a, int axis, bool track, int64_t* n_blocks)
+{
+    if (track) return launch<PIPE, true>(ctx, a, axis, n_blocks);
+    return launch<PIPE, false>(ctx, a, axis, n_blocks);
 }
 
 template <int SCHEME, int LIM, int PROJ, int EOS>
-int dispatch_exact(armon_ctx* ctx, const sweep_args& a, int axis, bool exact)
+int dispatch_exact(armon_ctx* ctx, const sweep_args& a, int axis, bool exact, bool track, int64_t* nb)
 {
-    if (exact) return launch<fused::Pipe<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis);
-    return launch<fused::PipeFast<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis);
+    if (exact) return dispatch_track<fused::Pipe<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis, track, nb);
+    return dispatch_track<fused::PipeFast<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis, track, nb);
 }
 
 template <int SCHEME, int LIM, int PROJ>
-int dispatch_eos(armon_ctx* ctx, const sweep_args& a, int axis, int eos, bool exact)
+int dispatch_eos(armon_ctx* ctx, const sweep_args& a, int axis, int eos, bool exact, bool track, int64_t* nb)
 {
     if (eos == ARMON_EOS_BIZARRIUM)
-        return dispatch_exact<SCHEME, LIM, PROJ, ARMON_EOS_BIZARRIUM>(ctx, a, axis, exact);
-    return dispatch_exact<SCHEME, LIM, PROJ, ARMON_EOS_PERFECT_GAS>(ctx, a, axis, exact);
+        return dispatch_exact<SCHEME, LIM, PROJ, ARMON_EOS_BIZARRIUM>(ctx, a, axis, exact, track, nb);
+    return dispatch_exact<SCHEME, LIM, PROJ, ARMON_EOS_PERFECT_GAS>(ctx, a, axis, exact, track, nb);
 }
 
 template <int SCHEME, int LIM>
-int dispatch_proj(armon_ctx* ctx, const sweep_args& a, int axis, int eos, int proj, bool exact)
+int dispatch_proj(armon_ctx* ctx, const sweep_args& a, int axis, int eos, int proj, bool exact, bool track, int64_t* nb)
 {
     if (proj == ARMON_PROJECTION_EULER_2ND)
-        return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER_2ND>(ctx, a, axis, eos, exact);
-    return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER>(ctx, a, axis, eos, exact);
+        return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER_2ND>(ctx, a, axis, eos, exact, track, nb);
+    return dispatch_eos<SCHEME, LIM, ARMON_PROJECTION_EULER>(ctx, a, axis, eos, exact, track, nb);
 }
 
 }  // namespace
@@ -508,6 +539,7 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     ARMON_REQUIRE(d->scheme != ARMON_SCHEME_GAD || (d->limiter >= ARMON_LIMITER_NONE && d->limiter <= ARMON_LIMITER_SUPERBEE),
                   "unknown limiter tag %d", d->limiter);
     ARMON_REQUIRE(d->nx > 0 && d->ny > 0, "empty block %lld x %lld", (long long)d->nx, (long long)d->ny);
+    ARMON_REQUIRE(d->nx < (1ll << 28) && d->ny < (1ll << 30), "block too large for 32-bit row offsets");
     const int lag = (d->scheme == ARMON_SCHEME_GAD ? 1 : 0) + (d->projection == ARMON_PROJECTION_EULER_2ND ? 1 : 0) + 2;
     ARMON_REQUIRE(d->nghost >= lag, "nghost = %d but this scheme/projection reads %d cells past the block", d->nghost, lag);
     const int64_t n_axis = d->axis == ARMON_AXIS_X ? d->nx : d->ny;
@@ -517,7 +549,10 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
                   "NULL state array");
     ARMON_REQUIRE(d->rho_in != d->rho_out && d->u_in != d->u_out && d->v_in != d->v_out && d->E_in != d->E_out,
                   "in and out arrays must not alias (ping-pong)");
+    ARMON_REQUIRE(d->x_kernel == 0 || d->x_kernel == 2 || d->x_kernel == 3, "unknown x_kernel form %d", d->x_kernel);
     const bool exact = d->exact != 0;
+    const bool track = d->dt_cfl_out != nullptr;
+    ARMON_REQUIRE(!track || (d->cfl_dx > 0 && d->cfl_dy > 0), "dt_cfl_out needs cfl_dx, cfl_dy > 0");
 
     sweep_args a;
     a.nx = d->nx;
@@ -546,16 +581,31 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     a.p_out = d->p_out;
     a.c_out = d->c_out;
     a.seg = X ? 512 : 128;
-    a.x_kernel = d->reserved;      // tuning/testing knob: 0 = default (spatial)
-
-    if (d->scheme == ARMON_SCHEME_GODUNOV)
-        return dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact);
-    switch (d->limiter) {
-    case ARMON_LIMITER_MINMOD:
-        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD>(ctx, a, d->axis, d->eos, d->projection, exact);
-    case ARMON_LIMITER_SUPERBEE:
-        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_SUPERBEE>(ctx, a, d->axis, d->eos, d->projection, exact);
-    default:
-        return dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact);
+    a.x_kernel = d->x_kernel;
+    a.partials = nullptr;
+    if (track) {
+        int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));
+        if (rc != ARMON_OK) return rc;
+        a.partials = ctx->partials;
     }
+
+    int64_t n_blocks = 0;
+    int rc;
+    if (d->scheme == ARMON_SCHEME_GODUNOV) {
+        rc = dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact, track, &n_blocks);
+    } else {
+        switch (d->limiter) {
+        case ARMON_LIMITER_MINMOD:
+            rc = dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD>(ctx, a, d->axis, d->eos, d->projection, exact, track, &n_blocks);
+            break;
+        case ARMON_LIMITER_SUPERBEE:
+            rc = dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_SUPERBEE>(ctx, a, d->axis, d->eos, d->projection, exact, track, &n_blocks);
+            break;
+        default:
+            rc = dispatch_proj<ARMON_SCHEME_GAD, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact, track, &n_blocks);
+        }
+    }
+    if (rc != ARMON_OK || !track) return rc;
+    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n_blocks, d->cfl_dx, d->cfl_dy, d->dt_cfl_out);
+    return check_launch("fold_dt");
 }

@@ -7,39 +7,20 @@
 // partials in a fixed order. No atomics: the sums are reproducible run to run, the min is exact.
 #include "common.hpp"
 #include "physics.hpp"
+#include "reduce.hpp"
 
 using namespace armon;
 
 namespace {
 
-constexpr int kWave = 64;
+using red::kWave;
+using red::op_min;
+using red::op_sum;
 
-struct op_min { __device__ static double id() { return INFINITY; } __device__ static double f(double a, double b) { return phys::mn(a, b); } };
-struct op_sum { __device__ static double id() { return 0.; } __device__ static double f(double a, double b) { return a + b; } };
-
-template <typename OP>
-__device__ __forceinline__ double wave_reduce(double v)
-{
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v = OP::f(v, __shfl_down(v, off, kWave));
-    return v;   // valid in lane 0
-}
-
-// Reduce across the workgroup; result valid in thread 0. `lds` holds kBlock/kWave doubles.
 template <typename OP>
 __device__ __forceinline__ double block_reduce(double v, double* lds)
 {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    v = wave_reduce<OP>(v);
-    if (lane == 0) lds[wave] = v;
-    __syncthreads();
-    double r = OP::id();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 0; w < kBlock / kWave; w++) r = OP::f(r, lds[w]);
-    }
-    __syncthreads();
-    return r;
+    return red::block_reduce<OP, kBlock / kWave>(v, lds, threadIdx.x);
 }
 
 // ---- a11: dtCFL (ref src/reductions.jl:2-53) -------------------------------------------------------

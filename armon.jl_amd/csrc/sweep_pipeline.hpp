@@ -55,6 +55,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     Upd l[4];                   // ring: updated cells cu, cu-1, cu-2   (cu = nf - 1)
     double s[2][4];             // minmod slopes of cells cu-1 / cu-2
     double a[2][4];             // advection fluxes at interfaces na / na-1
+    double csr[4];              // ring: sound speed of cells j .. j-3 (dt/CFL tracking only)
 
     __device__ __forceinline__ Pipe(double dt_, double dx_, double gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
     {
@@ -62,7 +63,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             c[k] = Cell{1., 0., 0., 1., 1., 1.};
-            gus[k] = 0.; gps[k] = 1.; fus[k] = 0.; fps[k] = 1.;
+            gus[k] = 0.; gps[k] = 1.; fus[k] = 0.; fps[k] = 1.; csr[k] = 1.;
             l[k] = Upd{1., 0., 0., 1., 0., 0., 1., dx_};
             s[0][k] = s[1][k] = 0.;
             a[0][k] = a[1][k] = 0.;
@@ -71,11 +72,13 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 
     // Feed cell j (pre-sweep state; Y_AXIS: ua is v and ut is u) and get the post-sweep state of cell
     // j - LAG. PH = step index mod 4. p_j, c_j: EOS of cell j, for optional materialisation.
+    // c_lag: the (pre-sweep) sound speed of the emitted cell j - LAG, for the fused dt/CFL reduction.
     template <bool Y_AXIS, int PH>
-    __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j)
+    __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j, double& c_lag)
     {
         constexpr int R0 = PH & 3, R1 = (PH - 1) & 3, R2 = (PH - 2) & 3, R3 = (PH - 3) & 3;
         constexpr int P0 = PH & 1, P1 = P0 ^ 1;
+        c_lag = csr[(PH - LAG) & 3];      // LAG = 4: this very slot, read before it is overwritten below
 
         // ---- EOS (ref src/kernels.jl:4-55): e = E - 0.5*(u² + v²) with u, v in the reference's order
         double p, cs;
@@ -90,6 +93,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         }
         p_j = p;
         c_j = cs;
+        csr[R0] = cs;
         c[R0] = Cell{rho, ua, ut, E, p, rho * cs};
         const Cell& c0 = c[R0];
         const Cell& c1 = c[R1];
@@ -286,6 +290,7 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     double isum[2];                         // 1 / (dxl[cu] + dxl[cu-1]) of this / the previous step
     double s[2][4];
     double a[2][4];
+    double csr[4];
 
     __device__ __forceinline__ PipeFast(double dt_, double dx_, double gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
     {
@@ -297,7 +302,7 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         for (int k = 0; k < 4; k++) {
             c[k] = Cell{1., 0., 0., 1., 1., 1.};
             gus[k] = 0.; gps[k] = 1.; src[k] = 2.;
-            fps[k] = 1.; dtu[k] = 0.; pu[k] = 0.;
+            fps[k] = 1.; dtu[k] = 0.; pu[k] = 0.; csr[k] = 1.;
             l[k] = Upd{1., 0., 0., 1., dx_, 0.5 / dx_, 0., 0., 0., 0.};
             s[0][k] = s[1][k] = 0.;
             a[0][k] = a[1][k] = 0.;
@@ -306,11 +311,12 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     }
 
     template <bool Y_AXIS, int PH>
-    __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j)
+    __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j, double& c_lag)
     {
         using namespace fast;
         constexpr int R0 = PH & 3, R1 = (PH - 1) & 3, R2 = (PH - 2) & 3, R3 = (PH - 3) & 3;
         constexpr int P0 = PH & 1, P1 = P0 ^ 1;
+        c_lag = csr[(PH - LAG) & 3];
 
         // ---- EOS
         double p, cs;
@@ -324,6 +330,7 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         }
         p_j = p;
         c_j = cs;
+        csr[R0] = cs;
         c[R0] = Cell{rho, ua, ut, E, p, rho * cs};
         const Cell& c0 = c[R0];
         const Cell& c1 = c[R1];

@@ -112,7 +112,8 @@ class BlockGrid:
         self.data = {f: dev.empty(n) for f in FIELDS}
         self.alt = {f: dev.empty(n) for f in STATE_VARS} if params.use_fused_sweep else None
         self.global_dt = GlobalTimeStep(params)
-        self.dt_scalar = dev.zeros(2)          # device scalar(s) written by the fused dt reduction
+        self.dt_scalar = dev.zeros(2)          # device scalar written by the fused dt reduction
+        self.dt_pending = False                # True when dt_scalar holds the CFL step of the current state
         self.comm = None                       # set by halo_exchange.setup when use_MPI
 
     def ptr(self, name):
@@ -315,9 +316,10 @@ def global_min(params, local_dt):
 
 # ---- fused sweep -----------------------------------------------------------------------------------
 
-def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False):
+def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=False):
     """One directional sweep as a single kernel launch (armon_hip_sweep). The halo cells of process
-    boundaries must already hold the neighbour's (ρ,u,v,E)."""
+    boundaries must already hold the neighbour's (ρ,u,v,E). ``emit_dt``: also reduce the CFL time step
+    of the resulting state into ``grid.dt_scalar`` (device)."""
     d = SweepDesc()
     d.axis = 0 if axis == Axis.X else 1
     d.scheme = SCHEMES[params.riemann_scheme]
@@ -329,6 +331,7 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False):
     d.bc_low = int(params.neighbours[lo] == PROC_NULL)
     d.bc_high = int(params.neighbours[hi] == PROC_NULL)
     d.exact = int(params.exact_arithmetic)
+    d.x_kernel = int(getattr(params, "x_kernel", 0))
     d.nx, d.ny = params.N
     d.dt, d.dx, d.gamma = dt, dx, params.test.gamma
     d.u_factor_low, d.v_factor_low = params.test.boundary_condition(lo)
@@ -337,6 +340,11 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False):
     d.rho_out, d.u_out, d.v_out, d.E_out = (grid.alt[f].ptr for f in STATE_VARS)
     d.p_out = grid.data["p"].ptr if emit_p else None
     d.c_out = grid.data["c"].ptr if emit_c else None
+    if emit_dt:
+        d.dt_cfl_out = grid.dt_scalar.ptr
+        d.cfl_dx = params.domain_size[0] / params.global_grid[0]
+        d.cfl_dy = params.domain_size[1] / params.global_grid[1]
+        grid.dt_pending = True
     with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
         check(_L().armon_hip_sweep(params.device.ctx, C.byref(d)))
     grid.swap_state()
@@ -349,14 +357,20 @@ def next_time_step(params, grid):
     gdt = grid.global_dt
     if params.cst_dt:
         return
-    local_dt = local_time_step(params, grid)
+    if grid.dt_pending:
+        # the last fused sweep of the previous cycle already reduced the CFL step of this state
+        local_dt = float(grid.dt_scalar.to_host()[0])
+        grid.dt_pending = False
+    else:
+        local_dt = local_time_step(params, grid)
     gdt.update_dt(global_min(params, local_dt))
 
 
-def solver_cycle(params, grid):
-    """ref src/solver.jl:288-320"""
+def solver_cycle(params, grid, last_cycle=True):
+    """ref src/solver.jl:288-320. ``last_cycle`` (fused path only): materialise p (the reference's
+    saved_vars hold the EOS of the state before the last sweep) after this cycle."""
     gdt = grid.global_dt
-    if gdt.cycle == 0:
+    if gdt.cycle == 0 and not grid.dt_pending:
         update_EOS(params, grid)
     next_time_step(params, grid)
     sweeps = split_axes(params.axis_splitting, gdt.cycle)
@@ -369,10 +383,12 @@ def solver_cycle(params, grid):
             if params.use_MPI:
                 from .halo_exchange import exchange_state_halo
                 exchange_state_halo(params, grid, axis)
-            # p and c of the pre-sweep state are what the reference leaves in memory after the last
-            # sweep of a cycle (ref SURVEY §3.4): materialise them there only.
+            # The last sweep of a cycle also reduces the next cycle's CFL step (post-sweep u, v with its
+            # own pre-sweep c: what the reference's dtCFL_kernel reads) and, on the final
+            # cycle, materialises the pre-sweep p that the reference leaves in memory.
             last = k == len(sweeps) - 1
-            fused_sweep(params, grid, axis, dt, dx, emit_p=last, emit_c=last)
+            fused_sweep(params, grid, axis, dt, dx, emit_p=last and last_cycle,
+                        emit_dt=last and not params.cst_dt)
         else:
             update_EOS(params, grid, axis)
             block_ghost_exchange(params, grid, axis)
@@ -384,11 +400,18 @@ def solver_cycle(params, grid):
 def time_loop(params, grid):
     """ref src/solver.jl:323-403 → (time, dt, cycles, cells_per_ns, solve_time_ns)"""
     grid.global_dt.reset()
+    grid.dt_pending = False
     gdt = grid.global_dt
     params.wait()
     t1 = _time.perf_counter_ns()
     while gdt.time < params.maxtime and gdt.cycle < params.maxcycle:
-        solver_cycle(params, grid)
+        if params.cst_dt:
+            ends = gdt.time + gdt.current_dt >= params.maxtime or gdt.cycle + 1 >= params.maxcycle
+        else:
+            # the cycle's dt is only known after next_time_step on cycle 0: be conservative there
+            ends = (gdt.cycle + 1 >= params.maxcycle or gdt.current_dt == 0
+                    or gdt.time + gdt.current_dt >= params.maxtime)
+        solver_cycle(params, grid, last_cycle=ends)
         gdt.next_cycle()
         if params.silent <= 1:
             params.wait()

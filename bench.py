@@ -144,13 +144,13 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        solver_cycle(params, grid)
+        solver_cycle(params, grid, last_cycle=False)
         gdt.next_cycle()
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        solver_cycle(params, grid)
+        solver_cycle(params, grid, last_cycle=False)
         gdt.next_cycle()
     barrier()
     elapsed = time.perf_counter() - t0

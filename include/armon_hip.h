@@ -207,8 +207,9 @@ typedef struct {
     int32_t bc_low, bc_high; /* 1: physical boundary on the low/high side of `axis` → mirror BC
                                 applied in-tile; 0: ghosts already hold neighbour data (halo)   */
     int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to staged  */
-    int32_t reserved;        /* X-sweep kernel form, for tests/tuning: 0 default (lanes along x, DPP
-                                shifts), 1 LDS-transposed march with 16-B accesses, 2 generic LDS march */
+    int32_t x_kernel;        /* X-sweep kernel form, for tests/tuning: 0 default (lanes along x, DPP
+                                shifts, 2 cells per lane), 3 same with 1 cell per lane, 2 LDS-transposed
+                                march                                                            */
     int64_t nx, ny;          /* real cells of the block                                         */
     double  dt, dx;          /* sweep time step (current_dt·factor) and cell size along axis    */
     double  gamma;           /* perfect gas only                                                */
@@ -217,6 +218,13 @@ typedef struct {
     double *rho_out, *u_out, *v_out, *E_out;
     double *p_out;           /* nullable: EOS pressure of the PRE-sweep state (real cells)      */
     double *c_out;           /* nullable: EOS sound speed of the PRE-sweep state (real cells)   */
+    /* Fused dt/CFL reduction of the NEXT cycle (ref src/reductions.jl:2-53, src/solver.jl:298): when
+     * dt_cfl_out is non-NULL the sweep also reduces min(cfl_dx/max|u±c|, cfl_dy/max|v±c|) over the real
+     * cells, with the post-sweep u, v and the pre-sweep c — exactly what dtCFL_kernel reads at the start
+     * of the next cycle when this is the last sweep of a cycle — into *dt_cfl_out (one
+     * device double, written by a follow-up fold kernel on the same stream). */
+    double *dt_cfl_out;
+    double  cfl_dx, cfl_dy;  /* GLOBAL cell sizes along x and y (ref src/reductions.jl:92)        */
 } armon_sweep_desc;
 
 ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);

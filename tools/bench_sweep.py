@@ -22,6 +22,7 @@ ap.add_argument("--scheme", default="GAD")
 ap.add_argument("--projection", default="euler_2nd")
 ap.add_argument("--emit", action="store_true")
 ap.add_argument("--modes", default="exact,fast")
+ap.add_argument("--xk", default="0", help="comma list of X kernel forms: 0 spatial K=2, 3 spatial K=1, 1 LDS vec, 2 LDS generic")
 args = ap.parse_args()
 ny = args.ny or args.n
 
@@ -37,13 +38,14 @@ res = {}
 for r in range(args.rounds + 1):
     for mode in args.modes.split(","):
         params.exact_arithmetic = mode == "exact"
-        for axis in (Axis.X, Axis.Y):
+        for axis, xk in [(Axis.X, int(k)) for k in args.xk.split(",")] + [(Axis.Y, 0)]:
+            params.x_kernel = xk
             dev.event_record(0)
             fused_sweep(params, grid, axis, dt, dx, emit_p=args.emit, emit_c=args.emit)
             dev.event_record(1)
             ms = dev.event_elapsed_ms(0, 1)
             if r > 0:
-                res.setdefault((mode, axis.name), []).append(ms)
+                res.setdefault((mode, axis.name + (str(xk) if axis == Axis.X else "")), []).append(ms)
     # keep the state sane (a few sweeps of Sod are harmless, but do not let it drift for long)
     if r % 3 == 2:
         init_test(params, grid)
