@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
 k_sweep_y(sweep_args a)
 {
     constexpr int LAG = PIPE::LAG;
-    constexpr int PF = 4;            // rows in flight per lane (= the unroll of the march)
+    constexpr int PF = 4;            // rows in flight per lane, ahead of the march
     const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
     const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x);
     const bool active = xr < nx;
@@ -158,16 +158,17 @@ k_sweep_y(sweep_args a)
     PIPE pipe(a.dt, a.dx, a.gamma);
     cfl_track cfl;
 
-    double pr[PF][4];                // prefetch ring: (ρ, ua, ut, E) of rows j .. j+PF-1
     int lj = jb;                     // next row to load and its offset from the run's first row
     unsigned lo_off = 0;
     unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;     // row j - LAG relative to row o0 (wraps until valid)
 
-    // CHECKED steps handle everything (mirrored / clamped loads, masked stores, p/c output); the steady
-    // state of a run uses the unchecked form: plain loads, unconditional stores, one basic block.
+    // The state of row lj is loaded straight into the pipeline's cell ring, slot lj mod 8, PF steps before
+    // the march reaches it. CHECKED steps handle everything (mirrored / clamped loads, masked stores,
+    // p/c output); the steady state of a run uses the unchecked form: plain loads, unconditional stores.
     auto load = [&](auto slot, auto checked) {
-        constexpr int K = decltype(slot)::value;
+        constexpr int K = decltype(slot)::value & 7;
         constexpr bool CHECKED = decltype(checked)::value;
+        auto& dst = pipe.c[K];
         if (CHECKED) {
             const bool m_lo = lj < 0 && a.bc_low, m_hi = lj >= ny && a.bc_high;     // uniform, rare
             // physical boundary: mirror of the inside (ref src/halo_exchange.jl:2-29)
@@ -175,30 +176,30 @@ k_sweep_y(sweep_args a)
             const unsigned off = (unsigned)(src - jb) * pitchb;
             const double fa = m_lo ? a.fa_low : (m_hi ? a.fa_high : 1.);
             const double ft = m_lo ? a.ft_low : (m_hi ? a.ft_high : 1.);
-            pr[K][0] = buf_load(r_rho, colb, off);
-            pr[K][1] = buf_load(r_ua, colb, off) * fa;
-            pr[K][2] = buf_load(r_ut, colb, off) * ft;
-            pr[K][3] = buf_load(r_E, colb, off);
+            dst.rho = buf_load(r_rho, colb, off);
+            dst.ua = buf_load(r_ua, colb, off) * fa;
+            dst.ut = buf_load(r_ut, colb, off) * ft;
+            dst.E = buf_load(r_E, colb, off);
             if (lj + 1 < je) {       // stay on the last row once the run is exhausted (padding steps)
                 lj++;
                 lo_off += pitchb;
             }
         } else {
-            pr[K][0] = buf_load(r_rho, colb, lo_off);
-            pr[K][1] = buf_load(r_ua, colb, lo_off);
-            pr[K][2] = buf_load(r_ut, colb, lo_off);
-            pr[K][3] = buf_load(r_E, colb, lo_off);
+            dst.rho = buf_load(r_rho, colb, lo_off);
+            dst.ua = buf_load(r_ua, colb, lo_off);
+            dst.ut = buf_load(r_ut, colb, lo_off);
+            dst.E = buf_load(r_E, colb, lo_off);
             lj++;
             lo_off += pitchb;
         }
     };
+    using std::integral_constant;
     auto step = [&](auto ph, auto checked, int j) {
-        constexpr int PH = decltype(ph)::value;
+        constexpr int PH8 = decltype(ph)::value;
         constexpr bool CHECKED = decltype(checked)::value;
-        const double rho = pr[PH][0], ua = pr[PH][1], ut = pr[PH][2], E = pr[PH][3];
-        load(ph, checked);           // refill this slot: PF rows ahead of the march
+        load(integral_constant<int, PH8 + PF>{}, checked);   // row j + PF → slot (j + PF) mod 8
         double p, c, c_lag;
-        const fused::Out4 out = pipe.template push<true, PH>(rho, ua, ut, E, p, c, c_lag);
+        const fused::Out4 out = pipe.template advance<true, PH8>(p, c, c_lag);
         const int o = j - LAG;
         if (CHECKED) {
             if (a.emit && j >= o0 && j < o1 && active) {
@@ -218,31 +219,23 @@ k_sweep_y(sweep_args a)
         }
         so_off += pitchb;
     };
-    using std::integral_constant;
-    auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 4
-        for (int t = t0; t < t1; t += 4) {
-            step(integral_constant<int, 0>{}, checked, jb + t);
-            step(integral_constant<int, 1>{}, checked, jb + t + 1);
-            step(integral_constant<int, 2>{}, checked, jb + t + 2);
-            step(integral_constant<int, 3>{}, checked, jb + t + 3);
-        }
+    auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 8
+        for (int t = t0; t < t1; t += 8)
+            static_for(std::make_integer_sequence<int, 8>{}, [&](auto ph) { step(ph, checked, jb + t + decltype(ph)::value); });
     };
 
     const int T = je - jb;                                   // steps of the run
-    const int T4 = (T + 3) & ~3;                             // … padded to the unroll
-    const int P = (2 * LAG + 3) & ~3;                        // after P steps every step emits a valid cell
+    const int T8 = (T + 7) & ~7;                             // … padded to the unroll
+    const int P = (2 * LAG + 7) & ~7;                        // after P steps every step emits a valid cell
     // last step (exclusive) whose prefetch needs neither mirroring nor clamping and whose store is valid
     const int plain_end = (a.bc_high && ny < je ? ny : je) - jb - PF;
-    int M = (T < plain_end ? T : plain_end) & ~3;
+    int M = (T < plain_end ? T : plain_end) & ~7;
     if (M < P || (a.emit & 3)) M = P;                        // p/c output: everything through the checked form
 
-    load(integral_constant<int, 0>{}, std::true_type{});
-    load(integral_constant<int, 1>{}, std::true_type{});
-    load(integral_constant<int, 2>{}, std::true_type{});
-    load(integral_constant<int, 3>{}, std::true_type{});
-    run(std::true_type{}, 0, P < T4 ? P : T4);
+    static_for(std::make_integer_sequence<int, PF>{}, [&](auto k) { load(k, std::true_type{}); });
+    run(std::true_type{}, 0, P < T8 ? P : T8);
     run(std::false_type{}, P, M);
-    run(std::true_type{}, M, T4);
+    run(std::true_type{}, M, T8);
 
     if (TRACK) cfl_block_store<kYBlock / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
@@ -401,27 +394,24 @@ k_sweep_x_lds(sweep_args a)
         __syncthreads();
         // -- march: lane walks its own row through the tile, results overwrite the consumed slots
         if (row_ok) {
-#pragma unroll 1
-            for (int t0 = 0; t0 < CH; t0 += 4) {
-                static_for(std::make_integer_sequence<int, 4>{}, [&](auto phc) {
-                    constexpr int PH = decltype(phc)::value;
-                    const int t = t0 + PH;
-                    const int64_t j = jb + t;
-                    if (j < j_end) {
-                        double p, c, c_lag;
-                        const fused::Out4 out = pipe.template push<false, PH>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c, c_lag);
-                        T(0, lane, t) = out.rho;
-                        T(1, lane, t) = out.ua;
-                        T(2, lane, t) = out.ut;
-                        T(3, lane, t) = out.E;
-                        if (emit) {
-                            T(4, lane, t) = p;
-                            T(5, lane, t) = c;
-                        }
-                        if (TRACK && j - LAG >= o0) cfl.add(out.ua, out.ut, c_lag);
+            static_assert(CH == 8, "the march is unrolled by the 8 slots of the pipeline's cell ring");
+            static_for(std::make_integer_sequence<int, 8>{}, [&](auto phc) {
+                constexpr int t = decltype(phc)::value;
+                const int64_t j = jb + t;
+                if (j < j_end) {
+                    double p, c, c_lag;
+                    const fused::Out4 out = pipe.template push<false, t>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c, c_lag);
+                    T(0, lane, t) = out.rho;
+                    T(1, lane, t) = out.ua;
+                    T(2, lane, t) = out.ut;
+                    T(3, lane, t) = out.E;
+                    if (emit) {
+                        T(4, lane, t) = p;
+                        T(5, lane, t) = c;
                     }
-                });
-            }
+                    if (TRACK && j - LAG >= o0) cfl.add(out.ua, out.ut, c_lag);
+                }
+            });
         }
         __syncthreads();
         // -- store phase: slot t holds the new state of column jb + t - LAG (and p, c of column jb + t)

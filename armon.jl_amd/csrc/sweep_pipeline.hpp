@@ -9,9 +9,14 @@
 // update, slope and advection is computed ONCE (the staged GAD kernel solves each interface three
 // times, ref src/riemann_schemes.jl:63-80).
 //
-// History lives in rings of 4 (2 for slopes / advection fluxes) indexed by the step's phase
-// PH = step mod 4, a template parameter: callers unroll the march by 4, every ring index is a
-// compile-time constant and no register is ever moved to "shift" the history.
+// History lives in rings indexed by the step's phase, a template parameter: callers unroll the march,
+// every ring index is a compile-time constant and no register is ever moved to "shift" the history.
+// The cell ring has 8 slots and doubles as the landing zone of the caller's prefetch: the state of
+// cell j is loaded straight into slot j mod 8 (up to 4 steps ahead) and stays there while the cell is
+// the "current", "previous" and "second previous" cell of the pipeline. A slot is only reloaded after
+// its last use, so no live value is ever copied (a reload overlapping a live value would force the
+// compiler to copy registers at the loop back-edge, and those copies wait for the loads in flight).
+// The other rings have 4 slots (2 for slopes / advection fluxes), indexed by the phase mod 4.
 //
 // Two arithmetic flavours with the same interface:
 //  * Pipe      — EXACT: the same IEEE operations in the same order as the staged kernels and the
@@ -49,7 +54,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     struct Upd { double rho, ua, ut, E, q_ua, q_ut, q_E, dxl; };   // Lagrangian (post cell_update) state
 
     double dt, dx, gamma;
-    Cell c[4];                  // ring: cells j, j-1, j-2
+    Cell c[8];                  // ring of 8: cells j+4 .. j (prefetched), j-1, j-2
     double gus[4], gps[4];      // ring: first-order solutions at interfaces j, j-1, j-2
     double fus[4], fps[4];      // ring: final fluxes at interfaces nf .. nf-3
     Upd l[4];                   // ring: updated cells cu, cu-1, cu-2   (cu = nf - 1)
@@ -61,8 +66,9 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     {
         // Neutral, finite start values: the first 2*LAG outputs are discarded by the caller.
 #pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = Cell{1., 0., 0., 1., 1., 1.};
+#pragma unroll
         for (int k = 0; k < 4; k++) {
-            c[k] = Cell{1., 0., 0., 1., 1., 1.};
             gus[k] = 0.; gps[k] = 1.; fus[k] = 0.; fps[k] = 1.; csr[k] = 1.;
             l[k] = Upd{1., 0., 0., 1., 0., 0., 1., dx_};
             s[0][k] = s[1][k] = 0.;
@@ -71,33 +77,44 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     }
 
     // Feed cell j (pre-sweep state; Y_AXIS: ua is v and ut is u) and get the post-sweep state of cell
-    // j - LAG. PH = step index mod 4. p_j, c_j: EOS of cell j, for optional materialisation.
+    // j - LAG. PH8 = step index mod 8. p_j, c_j: EOS of cell j, for optional materialisation.
     // c_lag: the (pre-sweep) sound speed of the emitted cell j - LAG, for the fused dt/CFL reduction.
-    template <bool Y_AXIS, int PH>
+    template <bool Y_AXIS, int PH8>
     __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j, double& c_lag)
     {
+        Cell& n = c[PH8 & 7];
+        n.rho = rho; n.ua = ua; n.ut = ut; n.E = E;
+        return advance<Y_AXIS, PH8>(p_j, c_j, c_lag);
+    }
+
+    // Same, with (ρ, ua, ut, E) of cell j already stored in c[PH8 & 7] by the caller's prefetch.
+    template <bool Y_AXIS, int PH8>
+    __device__ __forceinline__ Out4 advance(double& p_j, double& c_j, double& c_lag)
+    {
+        constexpr int PH = PH8 & 3;
         constexpr int R0 = PH & 3, R1 = (PH - 1) & 3, R2 = (PH - 2) & 3, R3 = (PH - 3) & 3;
         constexpr int P0 = PH & 1, P1 = P0 ^ 1;
         c_lag = csr[(PH - LAG) & 3];      // LAG = 4: this very slot, read before it is overwritten below
+        Cell& c0 = c[PH8 & 7];
+        const Cell& c1 = c[(PH8 - 1) & 7];
+        const Cell& c2 = c[(PH8 - 2) & 7];
 
         // ---- EOS (ref src/kernels.jl:4-55): e = E - 0.5*(u² + v²) with u, v in the reference's order
         double p, cs;
         {
-            const double u = Y_AXIS ? ut : ua, v = Y_AXIS ? ua : ut;
+            const double u = Y_AXIS ? c0.ut : c0.ua, v = Y_AXIS ? c0.ua : c0.ut;
             if (EOS == ARMON_EOS_BIZARRIUM) {
                 double g_unused;
-                phys::bizarrium<false>(rho, E, u, v, p, cs, g_unused);
+                phys::bizarrium<false>(c0.rho, c0.E, u, v, p, cs, g_unused);
             } else {
-                phys::perfect_gas(gamma, rho, E, u, v, p, cs);
+                phys::perfect_gas(gamma, c0.rho, c0.E, u, v, p, cs);
             }
         }
         p_j = p;
         c_j = cs;
         csr[R0] = cs;
-        c[R0] = Cell{rho, ua, ut, E, p, rho * cs};
-        const Cell& c0 = c[R0];
-        const Cell& c1 = c[R1];
-        const Cell& c2 = c[R2];
+        c0.p = p;
+        c0.rc = c0.rho * cs;
 
         // ---- first-order acoustic solve at interface j (ref src/riemann_schemes.jl:21-30)
         {
@@ -283,7 +300,7 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     struct Upd { double rho, q_ua, q_ut, q_E, dxl, hinv, d_rho, d_ua, d_ut, d_E; };
 
     double dt, dx, gamma, inv_dx, dt_dx, gm1, ggm1;
-    Cell c[4];
+    Cell c[8];
     double gus[4], gps[4], src[4];          // first-order solutions + (rc_l + rc_r) of the interface
     double fps[4], dtu[4], pu[4];           // final flux: pˢ, dt·uˢ, pˢ·uˢ at interfaces nf .. nf-3
     Upd l[4];
@@ -299,8 +316,9 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         gm1 = gamma_ - 1.;
         ggm1 = gamma_ * (gamma_ - 1.);
 #pragma unroll
+        for (int k = 0; k < 8; k++) c[k] = Cell{1., 0., 0., 1., 1., 1.};
+#pragma unroll
         for (int k = 0; k < 4; k++) {
-            c[k] = Cell{1., 0., 0., 1., 1., 1.};
             gus[k] = 0.; gps[k] = 1.; src[k] = 2.;
             fps[k] = 1.; dtu[k] = 0.; pu[k] = 0.; csr[k] = 1.;
             l[k] = Upd{1., 0., 0., 1., dx_, 0.5 / dx_, 0., 0., 0., 0.};
@@ -310,31 +328,41 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         isum[0] = isum[1] = 0.5 / dx_;
     }
 
-    template <bool Y_AXIS, int PH>
+    template <bool Y_AXIS, int PH8>
     __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j, double& c_lag)
     {
+        Cell& n = c[PH8 & 7];
+        n.rho = rho; n.ua = ua; n.ut = ut; n.E = E;
+        return advance<Y_AXIS, PH8>(p_j, c_j, c_lag);
+    }
+
+    template <bool Y_AXIS, int PH8>
+    __device__ __forceinline__ Out4 advance(double& p_j, double& c_j, double& c_lag)
+    {
         using namespace fast;
+        constexpr int PH = PH8 & 3;
         constexpr int R0 = PH & 3, R1 = (PH - 1) & 3, R2 = (PH - 2) & 3, R3 = (PH - 3) & 3;
         constexpr int P0 = PH & 1, P1 = P0 ^ 1;
         c_lag = csr[(PH - LAG) & 3];
+        Cell& c0 = c[PH8 & 7];
+        const Cell& c1 = c[(PH8 - 1) & 7];
+        const Cell& c2 = c[(PH8 - 2) & 7];
 
         // ---- EOS
         double p, cs;
         if (EOS == ARMON_EOS_BIZARRIUM) {
-            fast::bizarrium(rho, ua, ut, E, p, cs);
+            fast::bizarrium(c0.rho, c0.ua, c0.ut, c0.E, p, cs);
         } else {
             // p = (γ-1)ρe, c = sqrt(γp/ρ) = sqrt(γ(γ-1)e): no division
-            const double e = fma_(-0.5, fma_(ua, ua, ut * ut), E);
-            p = gm1 * rho * e;
+            const double e = fma_(-0.5, fma_(c0.ua, c0.ua, c0.ut * c0.ut), c0.E);
+            p = gm1 * c0.rho * e;
             cs = sqrt_(ggm1 * e);
         }
         p_j = p;
         c_j = cs;
         csr[R0] = cs;
-        c[R0] = Cell{rho, ua, ut, E, p, rho * cs};
-        const Cell& c0 = c[R0];
-        const Cell& c1 = c[R1];
-        const Cell& c2 = c[R2];
+        c0.p = p;
+        c0.rc = c0.rho * cs;
 
         // ---- first-order acoustic solve at interface j: one shared reciprocal
         {
