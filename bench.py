@@ -55,6 +55,20 @@ class EventTimer:
         return out
 
 
+def pmc_traffic(args, world):
+    """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_traffic_*.json, made by tools/pmc_to_traffic.py) — only for the exact workload
+    they were collected on; otherwise null."""
+    if world != 1 or args.staged or args.exact or args.n != 16384 or args.test != "Sod" or args.scheme != "GAD":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fused_fast_sod16384.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+        return round(sum(k["traffic_bytes_per_launch"] for k in ks.values()) / len(ks))
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = len(os.sched_getaffinity(0))
@@ -77,7 +91,7 @@ def cpu_baseline(test, scheme, target_seconds=12.0):
     O.solve(maxcycle=1, **kw)                                   # warm-up: page-touch + init
     run, _ = O.solve(maxcycle=2, **kw)
     per_cycle = run.solve_seconds / 2
-    cycles = int(max(2, min(40, target_seconds / max(per_cycle, 1e-6))))
+    cycles = int(max(2, min(400, target_seconds / max(per_cycle, 1e-6))))
     run, _ = O.solve(maxcycle=cycles, **kw)
     value = n * n * 2 * run.cycles / run.solve_seconds / 1e6
     return {"value": round(value, 2), "unit": "Mcells/s per sweep", "cores": cores, "kind": "port",
@@ -94,7 +108,10 @@ def main():
     ap.add_argument("--test", default="Sod")
     ap.add_argument("--scheme", default="GAD")
     ap.add_argument("--staged", action="store_true", help="5 staged kernels per sweep instead of the fused one")
-    ap.add_argument("--fast", action="store_true", help="tuned arithmetic (shared reciprocals, FMA)")
+    ap.add_argument("--exact", action="store_true",
+                    help="IEEE division/sqrt, no contraction (bit-identical to the CPU oracle) instead of the "
+                         "default tuned arithmetic (shared 1-ulp reciprocals + FMA, within the reference's tolerance)")
+    ap.add_argument("--fast", action="store_true", help="(default) tuned arithmetic; kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,7 +140,7 @@ def main():
         test=args.test, N=N_global, scheme=args.scheme, riemann_limiter="minmod", projection="euler_2nd",
         axis_splitting="Sequential", nghost=4, maxtime=1e9, maxcycle=10 ** 9, silent=5,
         use_MPI=world > 1, P=P, device_id=local_rank,
-        use_fused_sweep=not args.staged, exact_arithmetic=not args.fast)
+        use_fused_sweep=not args.staged, exact_arithmetic=args.exact)
     grid = BlockGrid(params)
     if world > 1:
         from armon_amd.halo_exchange import setup
@@ -173,7 +190,7 @@ def main():
     bpc = B_PER_CELL[dominant[0]]
     achieved = bpc * cells_local / (mean_ms * 1e-3) / 1e9 if all_ms else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args, world),
                 "kernel": "+".join(dominant), "bytes_per_cell": bpc, "launches_timed": len(all_ms),
                 "mean_launch_ms": round(mean_ms, 4),
                 "per_kernel_ms": {k: round(sum(v) / len(v), 4) for k, v in durs.items()}}
@@ -186,7 +203,8 @@ def main():
         "config": {"workload": f"{args.test} {N_global[0]}x{N_global[1]} fp64, {args.scheme}+minmod+euler_2nd, "
                                f"Sequential X,Y splitting, nghost 4, {args.n}x{args.n} cells per GPU",
                    "path": "staged (5 kernels/sweep)" if args.staged else "fused sweep",
-                   "arithmetic": "fast" if args.fast else "exact (IEEE div/sqrt, no contraction)",
+                   "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
+                   else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local},
         "hbm_GBps_algorithmic_whole_job": round(64 * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,

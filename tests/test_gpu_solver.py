@@ -18,7 +18,7 @@ def isapprox_count(a, b, atol=1e-13, rtol=4 * EPS):
 
 def run(test, N=(100, 100), **kw):
     import armon_amd
-    opts = dict(test=test, N=N, maxcycle=1000, silent=5, return_data=True)
+    opts = dict(test=test, N=N, maxcycle=1000, silent=5, return_data=True, exact_arithmetic=True)
     opts.update(kw)
     params = armon_amd.ArmonParameters(**opts)
     stats = armon_amd.armon(params)
@@ -91,7 +91,8 @@ def test_conservation(test, fused):
     """ref test/conservation.jl:1-16"""
     import armon_amd
     from armon_amd.solver import BlockGrid, conservation_vars, init_test, time_loop
-    params = armon_amd.ArmonParameters(test=test, N=(100, 100), maxcycle=10000, silent=5, use_fused_sweep=fused)
+    params = armon_amd.ArmonParameters(test=test, N=(100, 100), maxcycle=10000, silent=5, use_fused_sweep=fused,
+                                       exact_arithmetic=True)
     grid = BlockGrid(params)
     init_test(params, grid)
     m0, e0 = conservation_vars(params, grid)
@@ -118,7 +119,8 @@ def test_ghost_garbage_does_not_propagate(fused):
     from armon_amd.solver import BlockGrid, init_test, time_loop
     N = (32, 24)
     _, stats0, host0 = run("Sod_circ", N=N, maxcycle=12, use_fused_sweep=fused)
-    params = armon_amd.ArmonParameters(test="Sod_circ", N=N, maxcycle=12, silent=5, use_fused_sweep=fused)
+    params = armon_amd.ArmonParameters(test="Sod_circ", N=N, maxcycle=12, silent=5, use_fused_sweep=fused,
+                                       exact_arithmetic=True)
     grid = BlockGrid(params)
     init_test(params, grid)
     sx, sy = params.block_size.size
@@ -195,8 +197,9 @@ def test_fast_arithmetic_golden_and_conservation(test):
     t, dt, cycles, _, _ = time_loop(params, grid)
     m1, e1 = conservation_vars(params, grid)
     assert cycles == int(g["cycles"])
-    assert abs(dt - float(g["dt"])) <= 1e-12 * float(g["dt"])
+    assert abs(dt - float(g["dt"])) <= max(1e-13, 4 * EPS * float(g["dt"]))
     assert abs(m1 - m0) <= 1e-12 and abs(e1 - e0) <= 1e-12
     host = grid.device_to_host()
+    # the reference's own comparison rule (ref test/reference_data/reference_functions.jl:54-57)
     for k in ("rho", "u", "v", "p"):
-        assert np.abs(grid.real_view(host[k]) - g[k]).max() <= 1e-11 * np.abs(g[k]).max(), k
+        assert isapprox_count(grid.real_view(host[k]), g[k]) == 0, k

@@ -1,0 +1,218 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, and the host mirror of
+the reference interface (index math, ranges, parameters, dt state machine, splitting, process grid) behaves
+like the reference. Index tests follow ref test/blocking.jl:108-183 and test/domains.jl."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import armon_amd
+from armon_amd.blocking import Axis, BlockSize, DomainRange, Side, StepRange, axis_of, compute_steps_ranges
+from armon_amd.parameters import ArmonParameters, cart_coords, cart_neighbours, proc_grid_for
+from armon_amd.solver import GlobalTimeStep, split_axes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- the boundary ---------------------------------------------------------------------------------------
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "armon_hip.h")).read()
+    return sorted(set(re.findall(r"ARMON_API[^;]*?\b(armon_hip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_symbol_of_the_header():
+    import ctypes
+    syms = declared_symbols()
+    assert len(syms) >= 34
+    L = ctypes.CDLL(armon_amd.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/armon_hip.h but not exported"
+    # and the ctypes binding table covers exactly the same set
+    from armon_amd._lib import SIGNATURES
+    assert sorted(SIGNATURES) == syms
+
+
+def test_library_sanity_calls_without_gpu():
+    L = armon_amd.lib()
+    assert L.armon_hip_flt_size() == 8 and L.armon_hip_idx_size() == 8       # ref ext/ArmonKokkos.jl:122-139
+    assert b"gfx950" in L.armon_hip_version()
+
+
+def test_no_device_is_reported_not_hidden():
+    import ctypes as C
+    L = armon_amd.lib()
+    n = C.c_int(-1)
+    rc = L.armon_hip_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    assert L.armon_hip_init(0, None, C.byref(ctx)) == 3          # ARMON_ERR_NO_DEVICE
+    assert b"device" in L.armon_hip_last_error().lower()
+    with pytest.raises(armon_amd.SolverException):
+        ArmonParameters(test="Sod", N=(8, 8)).device              # no CPU fallback: creating the device raises
+
+
+# ---- BlockSize index math (ref test/blocking.jl:108-183) ------------------------------------------------------
+@pytest.mark.parametrize("size,g", [((64, 64), 5), ((37, 39), 5), ((64, 37), 5), ((37, 39), 1)])
+def test_block_size_index_math(size, g):
+    bs = BlockSize(size, g)
+    rs = bs.real_size
+    assert rs == (size[0] - 2 * g, size[1] - 2 * g)
+    full = bs.domain_range((-g, -g), (g, g))
+    assert full.size == size
+    for ij, j in enumerate(full.col, start=1):
+        for ii, i in enumerate(range(full.row.first + j - 1, full.row.stop + j), start=1):
+            I = (ii - g, ij - g)
+            assert bs.position(i) == I
+            assert bs.lin_position(I) == i
+            assert bs.is_ghost(i) == (any(c <= 0 for c in I) or any(I[d] > rs[d] for d in range(2)))
+    real = bs.domain_range()
+    assert real.size == rs
+    assert all(not bs.is_ghost(i) for i in real)
+    for side in Side:
+        border = bs.border_domain(side)
+        other = rs[1] if axis_of(side) == Axis.X else rs[0]
+        assert len(border) == other
+        assert border.size == ((1, other) if axis_of(side) == Axis.X else (other, 1))
+        gb = bs.ghost_domain(side, single_strip=False)
+        assert len(gb) == other * g
+        assert gb.size == ((g, other) if axis_of(side) == Axis.X else (other, g))
+        assert all(bs.is_ghost(i) for i in gb)
+        assert all(not bs.is_ghost(i) for i in bs.border_domain(side, single_strip=False))
+    assert bs.stride_along(Axis.X) == abs(bs.lin_position((1, 1)) - bs.lin_position((2, 1)))
+    assert bs.stride_along(Axis.Y) == abs(bs.lin_position((1, 1)) - bs.lin_position((1, 2)))
+    assert bs.size_along(Axis.X) == bs.size_along(Side.Left) == size[0]
+    assert bs.size_along(Axis.Y) == bs.size_along(Side.Top) == size[1]
+
+
+# ---- range utilities (ref test/domains.jl) ------------------------------------------------------------------
+@pytest.mark.parametrize("r,n", [(StepRange(1, 1, 10), 5), (StepRange(1, 50, 1051), 17)])
+def test_step_range_utilities(r, n):
+    assert len(r.shift(n)) == len(r) and r.shift(n).first == r.first + n * r.step
+    assert len(r.expand(n)) == len(r) + n and r.expand(n).first == r.first
+    assert len(r.prepend(n)) == len(r) + n and r.prepend(n).stop == r.stop
+    assert len(r.inflate(n)) == len(r) + 2 * n
+    assert len(r.expand(-len(r))) == 0 and len(r.prepend(1 - len(r))) == 1
+
+
+def test_domain_range_to_c_and_membership():
+    bs = BlockSize((108, 108), 4)
+    dr = bs.domain_range()
+    c = dr.to_c()
+    assert (c.col_start, c.col_step, c.col_len, c.row_start, c.row_len) == (436, 108, 100, 0, 100)
+    assert dr.first() in dr and dr.last() in dr and (dr.first() - 1) not in dr
+    g = bs.ghost_domain(Side.Left, single_strip=False).to_c()
+    assert g.row_start == -4 and g.row_len == 4          # rows shifted below 1: legal, first index still >= 0
+    assert g.col_start + g.row_start >= 0
+
+
+def test_steps_ranges_match_reference_table():
+    """ref src/parameters.jl:992-1025 with euler_2nd (w = 2)."""
+    sx = compute_steps_ranges(Axis.X, 4, 2)
+    assert sx.fluxes == ((-2, 0), (3, 0)) and sx.cell_update == ((-2, 0), (2, 0)) and sx.advection == ((0, 0), (1, 0))
+    sy = compute_steps_ranges(Axis.Y, 4, 1)
+    assert sy.fluxes == ((0, -1), (0, 2)) and sy.cell_update == ((0, -1), (0, 1)) and sy.advection == ((0, 0), (0, 1))
+    assert sx.EOS == sx.projection == sx.real_domain == ((0, 0), (0, 0)) and sx.full_domain == ((-4, -4), (4, 4))
+
+
+# ---- ArmonParameters (ref src/parameters.jl) ---------------------------------------------------------------
+def test_parameters_defaults_follow_the_test_case():
+    for test, cfl, maxtime, dom in [("Sod", 0.95, 0.20, (1., 1.)), ("Bizarrium", 0.6, 80e-6, (1., 1.)),
+                                    ("Sedov", 0.7, 1.0, (2., 2.))]:
+        p = ArmonParameters(test=test, N=(50, 40))
+        assert (p.cfl, p.maxtime, p.domain_size) == (cfl, maxtime, dom)
+        assert p.nghost == 4 and p.riemann_scheme == "GAD" and p.projection_scheme == "euler_2nd"
+        assert p.block_size.size == (58, 48) and p.N_origin == (1, 1) and p.global_grid == (50, 40)
+    p = ArmonParameters(test="Sedov", N=(100, 100))
+    assert p.test.r == math.hypot(0.02, 0.02) / math.sqrt(2)            # ref src/tests.jl:15-19
+    assert p.test.boundary_condition(Side.Left) == (1., 1.)
+    assert ArmonParameters(test="Sod").test.boundary_condition(Side.Left) == (-1., 1.)
+    assert ArmonParameters(test="Sod_y").test.boundary_condition(Side.Top) == (1., -1.)
+    assert ArmonParameters(test="Bizarrium").test.boundary_condition(Side.Right) == (1., 1.)
+
+
+@pytest.mark.parametrize("kw,category", [
+    (dict(test="Nope"), "config"),
+    (dict(scheme="WENO"), "config"),
+    (dict(riemann_limiter="vanleer"), "config"),
+    (dict(projection="euler_3rd"), "config"),
+    (dict(axis_splitting="Diagonal"), "config"),
+    (dict(nghost=3), "config"),                         # GAD + euler_2nd needs 4 (ref src/parameters.jl:609-613)
+    (dict(scheme="Godunov", projection="euler", nghost=1), "config"),   # stricter than the reference: see DESIGN §2
+    (dict(cst_dt=True, Dt=0.), "config"),
+    (dict(P=(1, 1, 1)), "config"),
+    (dict(use_gpu=False), "config"),
+    (dict(data_type=np.float32), "config"),
+])
+def test_parameters_reject_invalid_configurations(kw, category):
+    with pytest.raises(armon_amd.SolverException) as e:
+        ArmonParameters(**kw)
+    assert e.value.category == category
+
+
+def test_parameters_reject_unknown_options():
+    """ref src/parameters.jl:369-372"""
+    with pytest.raises(ValueError, match="unconsumed options"):
+        ArmonParameters(test="Sod", not_an_option=1)
+
+
+def test_reference_cpu_options_are_accepted():
+    """A reference script's kwargs run unchanged (the CPU-machinery knobs are inert on the device path)."""
+    p = ArmonParameters(test="Sod", N=(32, 32), use_threading=True, use_simd=True, numa_aware=False,
+                        lock_memory=False, busy_wait_limit=100, measure_time=True, silent=3,
+                        write_output=False, output_precision=None, animation_step=0, maxcycle=10)
+    assert p.maxcycle == 10 and p.use_fused_sweep and not p.exact_arithmetic
+
+
+# ---- dt state machine (ref src/solver_state.jl:102-166) ------------------------------------------
+def test_global_time_step_lag_and_growth_cap():
+    p = ArmonParameters(test="Sod", N=(8, 8), cfl=0.5)
+    g = GlobalTimeStep(p)
+    g.update_dt(1.0)                      # cycle 0: previous dt == 0 → dt0 = cfl·local, used at once
+    assert g.current_dt == 0.5 and g.next_cycle_dt == 0.5
+    g.next_cycle()
+    assert (g.cycle, g.time, g.current_dt) == (1, 0.5, 0.5)
+    g.update_dt(10.0)                     # cycle 1 still runs with dt0; growth capped at +5 %
+    assert g.current_dt == 0.5 and g.next_cycle_dt == 1.05 * 0.5
+    g.next_cycle()
+    assert g.current_dt == 1.05 * 0.5 and g.time == 1.0
+    g.update_dt(0.2)
+    assert g.next_cycle_dt == 0.1
+    for bad in (float("nan"), float("inf"), 0., -1.):
+        with pytest.raises(armon_amd.SolverException) as e:
+            g.update_dt(bad)
+        assert e.value.category == "time"
+
+
+def test_constant_dt():
+    p = ArmonParameters(test="Sod", N=(8, 8), cst_dt=True, Dt=1e-3)
+    g = GlobalTimeStep(p)
+    assert g.current_dt == 1e-3
+    g.next_cycle()
+    assert g.current_dt == 1e-3 and g.time == 1e-3
+
+
+def test_split_axes():
+    """ref src/axis_splitting.jl:24-46"""
+    X, Y = Axis.X, Axis.Y
+    assert split_axes("Sequential", 3) == ((X, 1.0), (Y, 1.0))
+    assert split_axes("Godunov", 0) == ((X, 1.0), (Y, 1.0)) and split_axes("SequentialSym", 1) == ((Y, 1.0), (X, 1.0))
+    assert split_axes("Strang", 0) == ((X, 0.5), (Y, 1.0), (X, 0.5)) and split_axes("Strang", 1) == ((Y, 0.5), (X, 1.0), (Y, 0.5))
+    assert split_axes("X_only", 5) == ((X, 1.0),) and split_axes("Y_only", 5) == ((Y, 1.0),)
+
+
+# ---- process grid (ref src/parameters.jl:408-467,673-697; test/mpi.jl:200-223) --------------------------------
+def test_cartesian_grid_and_neighbours():
+    dims = (4, 2)
+    assert [cart_coords(r, dims) for r in range(8)] == [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1)]
+    nb = cart_neighbours((0, 0), dims)
+    assert nb[Side.Left] == -1 and nb[Side.Bottom] == -1 and nb[Side.Right] == 2 and nb[Side.Top] == 1
+    nb = cart_neighbours((3, 1), dims)
+    assert nb[Side.Right] == -1 and nb[Side.Top] == -1 and nb[Side.Left] == 5 and nb[Side.Bottom] == 6
+    assert [proc_grid_for(w) for w in (1, 2, 4, 8)] == [(1, 1), (2, 1), (2, 2), (4, 2)]
+
+
+def test_memory_required():
+    assert armon_amd.memory_required((16384, 16384), 4) == 20 * 16392 * 16392 * 8
