@@ -1,0 +1,91 @@
+"""Worker functions for the multi-process tests (run under torch.multiprocessing.spawn)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank)
+    os.environ["WORLD_SIZE"] = str(world)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def halo_index_worker(rank, world, port, P, N_global, out_dir):
+    """Index-encoded halo exchange on the host (the design of ref test/mpi.jl:272-360): every cell of every
+    variable holds var·1e7 + its GLOBAL linear index; after the exchange each remote ghost cell must hold the
+    index of the neighbour's real cell it mirrors, physical-side ghosts stay untouched."""
+    import numpy as np
+    dist = _init(rank, world, port)
+    import armon_amd
+    from armon_amd.blocking import Axis, Side, sides_along
+    from armon_amd.halo_exchange import HaloExchanger, allreduce_min, allreduce_sum
+    from armon_amd.parameters import PROC_NULL
+
+    params = armon_amd.ArmonParameters(test="Sod", N=N_global, use_MPI=True, P=P)
+    bs, g = params.block_size, params.nghost
+    nx, ny = params.N
+    names = ("rho", "u", "v", "E", "p", "c", "g")
+    gx0, gy0 = params.N_origin[0] - 1, params.N_origin[1] - 1          # 0-based global position of the tile
+
+    def encode(vi):
+        a = np.full((ny + 2 * g, nx + 2 * g), -1.0)
+        iy, ix = np.mgrid[0:ny, 0:nx]
+        a[g:g + ny, g:g + nx] = vi * 1e7 + (gy0 + iy) * N_global[0] + (gx0 + ix)
+        return a.ravel()
+
+    arrays = {k: encode(vi) for vi, k in enumerate(names)}
+    ex = HaloExchanger(params, host_arrays=arrays)
+    errors = []
+    for axis in (Axis.X, Axis.Y):
+        ex.exchange(sides_along(axis), names)
+    for vi, k in enumerate(names):
+        a = arrays[k].reshape(ny + 2 * g, nx + 2 * g)
+        for j in range(-g, ny + g):
+            for i in range(-g, nx + g):
+                inside_x, inside_y = 0 <= i < nx, 0 <= j < ny
+                if inside_x and inside_y:
+                    continue
+                val = a[j + g, i + g]
+                side = None
+                if inside_y and i < 0: side = Side.Left
+                elif inside_y and i >= nx: side = Side.Right
+                elif inside_x and j < 0: side = Side.Bottom
+                elif inside_x and j >= ny: side = Side.Top
+                if side is not None and params.neighbours[side] != PROC_NULL:
+                    expected = vi * 1e7 + (gy0 + j) * N_global[0] + (gx0 + i)
+                else:
+                    expected = -1.0          # corners and physical sides are never written by the exchange
+                if val != expected:
+                    errors.append((k, i, j, val, expected))
+    mn = allreduce_min(params, float(rank + 1))
+    sm = allreduce_sum(params, (1.0, float(rank)))
+    ok = not errors and mn == 1.0 and sm == (float(world), float(sum(range(world))))
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("OK\n" if ok else f"FAIL {errors[:5]} {mn} {sm}\n")
+        f.write(f"{params.N} {params.N_origin} {params.cart_coords} {sorted((int(s), n) for s, n in params.neighbours.items())}\n")
+    dist.destroy_process_group()
+
+
+def gpu_solver_worker(rank, world, port, P, N_global, test, opts, out_dir):
+    """Tile-decomposed run on the GPU (all ranks share cuda:0, gloo transport with host staging): every rank
+    saves its tile so that the parent can compare with the single-process result."""
+    import numpy as np
+    dist = _init(rank, world, port)
+    import torch  # noqa: F401  (torch's HIP runtime must be the one the process uses)
+    import armon_amd
+    params = armon_amd.ArmonParameters(test=test, N=N_global, use_MPI=True, P=P, device_id=0, silent=5,
+                                       return_data=True, **opts)
+    stats = armon_amd.armon(params)
+    host = stats.data.device_to_host(("rho", "u", "v", "E", "p"))
+    np.savez(os.path.join(out_dir, f"tile{rank}.npz"), cycles=stats.cycles, dt=stats.last_dt, time=stats.final_time,
+             origin=np.array(params.N_origin), n=np.array(params.N),
+             **{k: stats.data.real_view(v) for k, v in host.items()})
+    dist.destroy_process_group()
