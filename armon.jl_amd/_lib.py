@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libarmon_hip.so")
+LIB_PATH = os.environ.get("ARMON_HIP_LIB") or os.path.join(_HERE, "libarmon_hip.so")   # env: A/B builds
 
 FIELDS = ("x", "y", "rho", "u", "v", "E", "p", "c", "g", "us", "ps",
           "work_1", "work_2", "work_3", "work_4", "mask")

@@ -127,6 +127,9 @@ k_fold_dt(const double* __restrict__ partials, int64_t n_blocks, double dx, doub
 
 // ---- Y sweep ---------------------------------------------------------------------------------------
 constexpr int kYBlock = 256;
+#ifndef ARMON_Y_PF
+#define ARMON_Y_PF 4             // rows prefetched ahead of the march (≤ 5: the cell ring has 8 slots)
+#endif
 #ifndef ARMON_Y_WAVES
 #define ARMON_Y_WAVES 2          // minimum waves per SIMD the Y march is compiled for (register budget)
 #endif
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
 k_sweep_y(sweep_args a)
 {
     constexpr int LAG = PIPE::LAG;
-    constexpr int PF = 4;            // rows in flight per lane, ahead of the march
+    constexpr int PF = ARMON_Y_PF;   // rows in flight per lane, ahead of the march
     const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
     const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x);
     const bool active = xr < nx;
@@ -270,14 +273,18 @@ k_sweep_x_dpp(sweep_args a, int niter)
     cfl_track cfl;
 
     const int64_t w_first = (int64_t)blockIdx.x * niter * STRIDE;
-    for (int it = 0; it < niter && row_ok; it++) {
-        const int64_t w0 = w_first + (int64_t)it * STRIDE;    // first cell this strip produces
-        if (w0 >= a.nx) break;
-        const int64_t cb = w0 - HALO;                         // first cell of the strip
-        const int64_t j0 = cb + (int64_t)lane * K;            // this lane's first cell
-
-        St rho, ua, ut, E;
-        const bool interior = cb >= 0 && cb + WIDTH <= a.nx;  // uniform: no ghost, no clamping
+    // Strips are double-buffered in registers: the loads of strip it+1 are issued before strip it is
+    // computed (the loop is unrolled by the two buffers, so no loaded register is ever copied).
+    St buf[2][4];
+    auto load_strip = [&](auto slot, int it) {
+        constexpr int B = decltype(slot)::value;
+        St& rho = buf[B][0];
+        St& ua = buf[B][1];
+        St& ut = buf[B][2];
+        St& E = buf[B][3];
+        const int64_t cb = w_first + (int64_t)it * STRIDE - HALO;     // first cell of the strip
+        const int64_t j0 = cb + (int64_t)lane * K;                    // this lane's first cell
+        const bool interior = cb >= 0 && cb + WIDTH <= a.nx;          // uniform: no ghost, no clamping
         if (interior && (K == 1 || vec_ok)) {
             if (K == 2) {
                 const double2 r = *reinterpret_cast<const double2*>(in[0] + j0);
@@ -305,9 +312,16 @@ k_sweep_x_dpp(sweep_args a, int niter)
                 E.v[k] = in[3][src];
             }
         }
+    };
+    auto strip_exists = [&](int it) { return it < niter && w_first + (int64_t)it * STRIDE < a.nx; };
+    auto do_strip = [&](auto slot, int it) {
+        constexpr int B = decltype(slot)::value;
+        if (strip_exists(it + 1)) load_strip(std::integral_constant<int, 1 - B>{}, it + 1);
+        const int64_t w0 = w_first + (int64_t)it * STRIDE;    // first cell this strip produces
+        const int64_t j0 = w0 - HALO + (int64_t)lane * K;
 
         St o_rho, o_u, o_v, o_E, p, cs;
-        sw.run(rho, ua, ut, E, o_rho, o_u, o_v, o_E, p, cs);
+        sw.run(buf[B][0], buf[B][1], buf[B][2], buf[B][3], o_rho, o_u, o_v, o_E, p, cs);
 
         // cells this lane may store: inside the strip's valid window and inside the block
         const int64_t hi = (w0 + STRIDE < a.nx) ? w0 + STRIDE : a.nx;
@@ -338,6 +352,14 @@ k_sweep_x_dpp(sweep_args a, int niter)
                     if (TRACK) cfl.add(o_u.v[k], o_v.v[k], cs.v[k]);
                 }
             }
+        }
+    };
+    if (row_ok && strip_exists(0)) {
+        load_strip(std::integral_constant<int, 0>{}, 0);
+        for (int it = 0; strip_exists(it); it += 2) {
+            do_strip(std::integral_constant<int, 0>{}, it);
+            if (!strip_exists(it + 1)) break;
+            do_strip(std::integral_constant<int, 1>{}, it + 1);
         }
     }
     if (TRACK)
@@ -570,7 +592,8 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     a.E_out = d->E_out;
     a.p_out = d->p_out;
     a.c_out = d->c_out;
-    a.seg = X ? 512 : 128;
+    static const int seg_y_env = getenv("ARMON_Y_SEG") ? atoi(getenv("ARMON_Y_SEG")) : 0;        // tuning knob
+    a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : 128);
     a.x_kernel = d->x_kernel;
     a.partials = nullptr;
     if (track) {

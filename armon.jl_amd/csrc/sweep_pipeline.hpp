@@ -234,6 +234,14 @@ __device__ __forceinline__ double rcp(double x)
     return __builtin_fma(r, e, r);
 }
 
+// 1/x to ≈2e-15 (one Newton step): for the reciprocals that only feed second-order correction terms
+// (limited GAD ratios, θ, slope ratios), where a relative error of 1e-15 is far below their truncation error.
+__device__ __forceinline__ double rcp1(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+
 // sqrt(x) to ≈1-2 ulp: v_rsq_f64 + two coupled Newton (Goldschmidt) steps; sqrt(0) = 0.
 __device__ __forceinline__ double sqrt_(double x)
 {
@@ -259,9 +267,10 @@ __device__ __forceinline__ double limiter(double r)
 }
 
 // minmod(a, b) = sign·min(|a|,|b|) when a·b > 0, else 0  (== slope_minmod of ref projection_schemes.jl:15-20)
+// = the median of (a, b, 0).
 __device__ __forceinline__ double minmod(double a, double b)
 {
-    return __builtin_fmax(0., __builtin_fmin(a, b)) + __builtin_fmin(0., __builtin_fmax(a, b));
+    return __builtin_fmax(__builtin_fmin(a, b), __builtin_fmin(__builtin_fmax(a, b), 0.));
 }
 
 // ref src/kernels.jl:16-55 with the four divisions by (1 - s·x) and the two by ρ shared
@@ -380,12 +389,12 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
             const double gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
             const double Au = gus1 - c2.ua, Bu = c1.ua - gus1;     // (uˢ_i - u[i-s]), (u[i] - uˢ_i)
             const double Ap = gps1 - c2.p, Bp = c1.p - gps1;
-            const double r_um = limiter<LIM>((gus0 - c1.ua) * rcp(Au + 1e-6));
-            const double r_pm = limiter<LIM>((gps0 - c1.p) * rcp(Ap + 1e-6));
-            const double r_up = limiter<LIM>((c2.ua - gus2) * rcp(Bu + 1e-6));
-            const double r_pp = limiter<LIM>((c2.p - gps2) * rcp(Bp + 1e-6));
+            const double r_um = limiter<LIM>((gus0 - c1.ua) * rcp1(Au + 1e-6));
+            const double r_pm = limiter<LIM>((gps0 - c1.p) * rcp1(Ap + 1e-6));
+            const double r_up = limiter<LIM>((c2.ua - gus2) * rcp1(Bu + 1e-6));
+            const double r_pp = limiter<LIM>((c2.p - gps2) * rcp1(Bp + 1e-6));
             // θ = ½(1 - (rc_l+rc_r)/2 · dt/Dm), Dm = dx(ρ_l+ρ_r)/2  →  ½ - ½·(rc_l+rc_r)·(dt/dx)/(ρ_l+ρ_r)
-            const double theta = fma_(-0.5 * src[R1] * dt_dx, rcp(c2.rho + c1.rho), 0.5);
+            const double theta = fma_(-0.5 * src[R1] * dt_dx, rcp1(c2.rho + c1.rho), 0.5);
             fus0 = fma_(theta, fma_(r_up, Bu, -r_um * Au), gus1);
             fps[R0] = fma_(theta, fma_(r_pp, Bp, -r_pm * Ap), gps1);
         } else {
@@ -423,7 +432,7 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 
         if (W == 1) {
             // slopes of cell cu-1: r₊ = 2Δx/(Δx+Δx₊), r₋ = 2Δx/(Δx+Δx₋); the second sum is last step's first
-            isum[P0] = rcp(l1.dxl + l0.dxl);
+            isum[P0] = rcp1(l1.dxl + l0.dxl);
             const double two_dxl = 2. * l1.dxl;
             const double r_p = two_dxl * isum[P0], r_m = two_dxl * isum[P1];
             s[P0][0] = minmod(r_p * l0.d_rho, r_m * l1.d_rho);

@@ -20,21 +20,22 @@
 namespace armon {
 namespace fused {
 
-// value of the previous lane (cell i-1 for K = 1); lane 0 keeps its own value
+// value of the previous lane (cell i-1 for K = 1). Lane 0 has no source and reads 0 (bound_ctrl): it
+// is a halo lane whose results are discarded, and not keeping its own value saves a register copy per shift.
 __device__ __forceinline__ double from_prev_lane(double x)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
-// value of the next lane; lane 63 keeps its own value
+// value of the next lane; lane 63 reads 0
 __device__ __forceinline__ double from_next_lane(double x)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -241,11 +242,11 @@ struct SpatialSweep {
             for (int k = 0; k < K; k++) {
                 const double Au = gus[k] - uL[k], Bu = ua[k] - gus[k];
                 const double Ap = gps[k] - pL[k], Bp = p[k] - gps[k];
-                const double r_um = limiter<LIM>((gusR[k] - ua[k]) * rcp(Au + 1e-6));
-                const double r_pm = limiter<LIM>((gpsR[k] - p[k]) * rcp(Ap + 1e-6));
-                const double r_up = limiter<LIM>((uL[k] - gusL[k]) * rcp(Bu + 1e-6));
-                const double r_pp = limiter<LIM>((pL[k] - gpsL[k]) * rcp(Bp + 1e-6));
-                const double theta = fma_(-0.5 * src[k] * dt_dx, rcp(rhoL[k] + rho[k]), 0.5);
+                const double r_um = limiter<LIM>((gusR[k] - ua[k]) * rcp1(Au + 1e-6));
+                const double r_pm = limiter<LIM>((gpsR[k] - p[k]) * rcp1(Ap + 1e-6));
+                const double r_up = limiter<LIM>((uL[k] - gusL[k]) * rcp1(Bu + 1e-6));
+                const double r_pp = limiter<LIM>((pL[k] - gpsL[k]) * rcp1(Bp + 1e-6));
+                const double theta = fma_(-0.5 * src[k] * dt_dx, rcp1(rhoL[k] + rho[k]), 0.5);
                 fus.v[k] = fma_(theta, fma_(r_up, Bu, -r_um * Au), gus[k]);
                 fps.v[k] = fma_(theta, fma_(r_pp, Bp, -r_pm * Ap), gps[k]);
             }
@@ -283,8 +284,8 @@ struct SpatialSweep {
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const double two_dxl = 2. * dxl[k];
-                const double r_m = two_dxl * rcp(dxl[k] + dxlL[k]);
-                const double r_p = two_dxl * rcp(dxl[k] + dxlR[k]);
+                const double r_m = two_dxl * rcp1(dxl[k] + dxlL[k]);
+                const double r_p = two_dxl * rcp1(dxl[k] + dxlR[k]);
                 s0.v[k] = minmod(r_p * (rR[k] - l_rho[k]), r_m * (l_rho[k] - rL[k]));
                 s1.v[k] = minmod(r_p * (quR[k] - q_ua[k]), r_m * (q_ua[k] - quL[k]));
                 s2.v[k] = minmod(r_p * (qvR[k] - q_ut[k]), r_m * (q_ut[k] - qvL[k]));

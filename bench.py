@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=16384, help="cells per axis PER GPU (weak scaling)")
+    ap.add_argument("--cells", type=int, default=16384, dest="n", help="cells per axis PER GPU (weak scaling)")
     ap.add_argument("--test", default="Sod")
     ap.add_argument("--scheme", default="GAD")
     ap.add_argument("--staged", action="store_true", help="5 staged kernels per sweep instead of the fused one")
@@ -127,8 +127,15 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # Rehearsal knob (one-GPU box): ARMON_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo with host
+        # staging, to exercise this code path; real runs use one GPU per rank over RCCL.
+        rehearsal = os.environ.get("ARMON_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import armon_amd
     from armon_amd.parameters import proc_grid_for
@@ -175,7 +182,7 @@ def main():
 
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -203,3 +203,30 @@ def test_fast_arithmetic_golden_and_conservation(test):
     # the reference's own comparison rule (ref test/reference_data/reference_functions.jl:54-57)
     for k in ("rho", "u", "v", "p"):
         assert isapprox_count(grid.real_view(host[k]), g[k]) == 0, k
+
+
+# ---- alternative X-sweep kernel forms and p/c materialisation on an X sweep ---------------------------------
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+@pytest.mark.parametrize("xk", [2, 3], ids=["lds_march", "dpp_k1"])
+@pytest.mark.parametrize("test,N,opts", [
+    ("Sod_circ", (67, 41), dict(maxcycle=15)),
+    ("Sod_circ", (130, 40), dict(maxcycle=10, axis_splitting="Godunov")),     # odd cycles end with an X sweep
+    ("Sod", (64, 8), dict(maxcycle=10, axis_splitting="X_only")),
+    ("Bizarrium", (64, 32), dict(maxcycle=12, scheme="Godunov")),
+])
+def test_alternative_x_kernels(oracle, test, N, opts, xk, exact):
+    import armon_amd
+    params = armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True, exact_arithmetic=exact, **opts)
+    params.x_kernel = xk
+    stats = armon_amd.armon(params)
+    host = stats.data.device_to_host()
+    orun, f = oracle.solve(test=test, N=N, **opts)
+    assert stats.cycles == orun.cycles
+    for k in ("rho", "u", "v", "E", "p"):
+        a = stats.data.real_view(host[k])
+        b = oracle.real_view(f[k], N[0], N[1], 4)
+        if exact:
+            assert np.array_equal(a, b), k
+        else:
+            assert np.abs(a - b).max() <= 1e-11 * max(np.abs(b).max(), 1e-300), k
+    assert (stats.last_dt == orun.last_dt) if exact else abs(stats.last_dt - orun.last_dt) <= 1e-12 * orun.last_dt

@@ -21,6 +21,7 @@ ap.add_argument("--test", default="Sod")
 ap.add_argument("--scheme", default="GAD")
 ap.add_argument("--projection", default="euler_2nd")
 ap.add_argument("--emit", action="store_true")
+ap.add_argument("--track", action="store_true", help="fused dt/CFL reduction on the Y sweep")
 ap.add_argument("--modes", default="exact,fast")
 ap.add_argument("--xk", default="0", help="comma list of X kernel forms: 0 spatial K=2, 3 spatial K=1, 1 LDS vec, 2 LDS generic")
 args = ap.parse_args()
@@ -41,7 +42,7 @@ for r in range(args.rounds + 1):
         for axis, xk in [(Axis.X, int(k)) for k in args.xk.split(",")] + [(Axis.Y, 0)]:
             params.x_kernel = xk
             dev.event_record(0)
-            fused_sweep(params, grid, axis, dt, dx, emit_p=args.emit, emit_c=args.emit)
+            fused_sweep(params, grid, axis, dt, dx, emit_p=args.emit, emit_c=args.emit, emit_dt=args.track and axis == Axis.Y)
             dev.event_record(1)
             ms = dev.event_elapsed_ms(0, 1)
             if r > 0:
