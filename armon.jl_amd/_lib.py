@@ -54,7 +54,8 @@ class SweepDesc(C.Structure):
                 ("rho_in", C.c_void_p), ("u_in", C.c_void_p), ("v_in", C.c_void_p), ("E_in", C.c_void_p),
                 ("rho_out", C.c_void_p), ("u_out", C.c_void_p), ("v_out", C.c_void_p), ("E_out", C.c_void_p),
                 ("p_out", C.c_void_p), ("c_out", C.c_void_p),
-                ("dt_cfl_out", C.c_void_p), ("cfl_dx", C.c_double), ("cfl_dy", C.c_double)]
+                ("dt_cfl_out", C.c_void_p), ("cfl_dx", C.c_double), ("cfl_dy", C.c_double),
+                ("out_lo", C.c_int64), ("out_hi", C.c_int64), ("dt_accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

@@ -34,6 +34,7 @@ struct sweep_args {
     int32_t emit;                  // bit 0: write p_out, bit 1: write c_out
     int32_t seg;                   // cells per run along the sweep axis (marching kernels)
     int32_t x_kernel;              // X sweep form: 0 spatial K=2, 3 spatial K=1, 2 LDS-transposed march
+    int64_t o_lo, o_hi;            // cells to produce along the sweep axis: [o_lo, o_hi)
     double dt, dx, gamma;
     double fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const double *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
@@ -112,7 +113,8 @@ __device__ __forceinline__ void cfl_block_store(const cfl_track& t, double* part
 }
 
 __global__ void __launch_bounds__(256)
-k_fold_dt(const double* __restrict__ partials, int64_t n_blocks, double dx, double dy, double* __restrict__ out)
+k_fold_dt(const double* __restrict__ partials, int64_t n_blocks, double dx, double dy, double* __restrict__ out,
+          int accumulate)
 {
     __shared__ double lds[4];
     double au = 0., av = 0.;
@@ -122,7 +124,10 @@ k_fold_dt(const double* __restrict__ partials, int64_t n_blocks, double dx, doub
     }
     au = red::block_reduce<red::op_max, 4>(au, lds, threadIdx.x);
     av = red::block_reduce<red::op_max, 4>(av, lds, threadIdx.x);
-    if (threadIdx.x == 0) out[0] = phys::mn(dx / au, dy / av);
+    if (threadIdx.x == 0) {
+        const double dt = phys::mn(dx / au, dy / av);
+        out[0] = accumulate ? phys::mn(out[0], dt) : dt;
+    }
 }
 
 // ---- Y sweep ---------------------------------------------------------------------------------------
@@ -144,8 +149,9 @@ k_sweep_y(sweep_args a)
     const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x);
     const bool active = xr < nx;
     const int x = active ? xr : nx - 1;          // idle lanes shadow the last column and never store
-    const int o0 = (int)blockIdx.y * a.seg;
-    const int o1 = (o0 + a.seg < ny) ? o0 + a.seg : ny;
+    const int o_hi = (int)a.o_hi;
+    const int o0 = (int)a.o_lo + (int)blockIdx.y * a.seg;
+    const int o1 = (o0 + a.seg < o_hi) ? o0 + a.seg : o_hi;
     const int jb = o0 - LAG, je = o1 + LAG;
 
     // Descriptors are based at the first row this run touches, so every scalar row offset is a small
@@ -267,12 +273,12 @@ k_sweep_x_dpp(sweep_args a, int niter)
     const int64_t row_off = (row + a.g) * a.row_len + a.g;
     const double* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
     double* out[4] = {a.rho_out + row_off, a.ua_out + row_off, a.ut_out + row_off, a.E_out + row_off};
-    const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && (a.g % 2 == 0);   // uniform
+    const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && (a.g % 2 == 0) && (a.o_lo % 2 == 0);   // uniform
 
     SW sw{a.dt, a.dx, a.gamma};
     cfl_track cfl;
 
-    const int64_t w_first = (int64_t)blockIdx.x * niter * STRIDE;
+    const int64_t w_first = a.o_lo + (int64_t)blockIdx.x * niter * STRIDE;
     // Strips are double-buffered in registers: the loads of strip it+1 are issued before strip it is
     // computed (the loop is unrolled by the two buffers, so no loaded register is ever copied).
     St buf[2][4];
@@ -313,7 +319,7 @@ k_sweep_x_dpp(sweep_args a, int niter)
             }
         }
     };
-    auto strip_exists = [&](int it) { return it < niter && w_first + (int64_t)it * STRIDE < a.nx; };
+    auto strip_exists = [&](int it) { return it < niter && w_first + (int64_t)it * STRIDE < a.o_hi; };
     auto do_strip = [&](auto slot, int it) {
         constexpr int B = decltype(slot)::value;
         if (strip_exists(it + 1)) load_strip(std::integral_constant<int, 1 - B>{}, it + 1);
@@ -324,7 +330,7 @@ k_sweep_x_dpp(sweep_args a, int niter)
         sw.run(buf[B][0], buf[B][1], buf[B][2], buf[B][3], o_rho, o_u, o_v, o_E, p, cs);
 
         // cells this lane may store: inside the strip's valid window and inside the block
-        const int64_t hi = (w0 + STRIDE < a.nx) ? w0 + STRIDE : a.nx;
+        const int64_t hi = (w0 + STRIDE < a.o_hi) ? w0 + STRIDE : a.o_hi;
         if (K == 2 && vec_ok && j0 >= w0 && j0 + 1 < hi) {
             *reinterpret_cast<double2*>(out[0] + j0) = double2{o_rho.v[0], o_rho.v[K - 1]};
             *reinterpret_cast<double2*>(out[1] + j0) = double2{o_u.v[0], o_u.v[K - 1]};
@@ -382,8 +388,8 @@ k_sweep_x_lds(sweep_args a)
 
     const int lane = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * kXRows;
-    const int64_t o0 = (int64_t)blockIdx.x * a.seg;
-    const int64_t o1 = (o0 + a.seg < a.nx) ? o0 + a.seg : a.nx;
+    const int64_t o0 = a.o_lo + (int64_t)blockIdx.x * a.seg;
+    const int64_t o1 = (o0 + a.seg < a.o_hi) ? o0 + a.seg : a.o_hi;
     const int64_t j_end = o1 + LAG;
     const bool row_ok = (r0 + lane) < a.ny;
     const bool emit = a.emit != 0;
@@ -469,14 +475,15 @@ k_sweep_x_lds(sweep_args a)
 template <class PIPE, bool TRACK>
 int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
 {
+    const int64_t n_out = a.o_hi - a.o_lo;
     if (axis == ARMON_AXIS_Y) {
-        dim3 grid((unsigned)((a.nx + kYBlock - 1) / kYBlock), (unsigned)((a.ny + a.seg - 1) / a.seg));
+        dim3 grid((unsigned)((a.nx + kYBlock - 1) / kYBlock), (unsigned)((n_out + a.seg - 1) / a.seg));
         *n_blocks = (int64_t)grid.x * grid.y;
         hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
         return check_launch("sweep_y");
     }
     if (a.x_kernel == 2) {
-        dim3 grid((unsigned)((a.nx + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
+        dim3 grid((unsigned)((n_out + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
         *n_blocks = (int64_t)grid.x * grid.y;
         const size_t lds = (size_t)(a.emit ? 6 : 4) * kXRows * (kXChunk + 1) * sizeof(double);
         hipLaunchKernelGGL((k_sweep_x_lds<PIPE, kXChunk, TRACK>), grid, dim3(kXRows), lds, ctx->stream, a);
@@ -487,7 +494,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     const bool k1 = a.x_kernel == 3;
     const int halo = k1 ? PIPE::LAG : ((PIPE::LAG + 1) & ~1);
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
-    dim3 grid((unsigned)((a.nx + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
+    dim3 grid((unsigned)((n_out + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
     *n_blocks = (int64_t)grid.x * grid.y;
     if (k1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
@@ -595,6 +602,14 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     static const int seg_y_env = getenv("ARMON_Y_SEG") ? atoi(getenv("ARMON_Y_SEG")) : 0;        // tuning knob
     a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : 128);
     a.x_kernel = d->x_kernel;
+    a.o_lo = 0;
+    a.o_hi = n_axis;
+    if (d->out_hi != 0) {
+        ARMON_REQUIRE(d->out_lo >= 0 && d->out_lo < d->out_hi && d->out_hi <= n_axis,
+                      "invalid partial sweep [%lld, %lld) of %lld cells", (long long)d->out_lo, (long long)d->out_hi, (long long)n_axis);
+        a.o_lo = d->out_lo;
+        a.o_hi = d->out_hi;
+    }
     a.partials = nullptr;
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));
@@ -619,6 +634,6 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
         }
     }
     if (rc != ARMON_OK || !track) return rc;
-    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n_blocks, d->cfl_dx, d->cfl_dy, d->dt_cfl_out);
+    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n_blocks, d->cfl_dx, d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
     return check_launch("fold_dt");
 }

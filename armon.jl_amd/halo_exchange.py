@@ -81,12 +81,14 @@ class HaloExchanger:
                                                      len(names), self._vars_ptrs(names)))
 
     # -- exchange ---------------------------------------------------------------------------------------
-    def exchange(self, sides, names):
-        """start_exchange + finish_exchange of the reference for every remote side in ``sides``."""
+    def start(self, sides, names):
+        """start_exchange of the reference (ref src/halo_exchange.jl:229-250) for every remote side in
+        ``sides``: pack, wait for the pack, post all sends and receives as one batch. Returns a handle for
+        ``finish``; device work enqueued in between overlaps with the transfers."""
         dist, torch, p = self.dist, self.torch, self.params
         sides = [s for s in sides if p.neighbours[s] != PROC_NULL]
         if not sides:
-            return
+            return None
         bs = p.block_size
         for s in sides:
             self.pack(s, names)
@@ -102,7 +104,15 @@ class HaloExchanger:
             peer = p.neighbours[s]
             ops.append(dist.P2POp(dist.isend, send, peer, self.group, tag=int(s)))
             ops.append(dist.P2POp(dist.irecv, recv, peer, self.group, tag=int(_opposite(s))))
-        for req in dist.batch_isend_irecv(ops):
+        return sides, names, staged, dist.batch_isend_irecv(ops)
+
+    def finish(self, handle):
+        """finish_exchange (ref src/halo_exchange.jl:264-283): wait for the transfers, unpack into the ghosts."""
+        if handle is None:
+            return
+        torch, p = self.torch, self.params
+        sides, names, staged, reqs = handle
+        for req in reqs:
             req.wait()
         for s in sides:
             if s in staged:
@@ -112,6 +122,9 @@ class HaloExchanger:
             torch.cuda.synchronize(p.device_id)       # receives landed before the unpack kernels read them
         for s in sides:
             self.unpack(s, names)
+
+    def exchange(self, sides, names):
+        self.finish(self.start(sides, names))
 
 
 def _opposite(side):

@@ -316,7 +316,13 @@ def global_min(params, local_dt):
 
 # ---- fused sweep -----------------------------------------------------------------------------------
 
-def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=False):
+def sweep_lag(params):
+    """Cells a fused sweep reads past the cells it writes: 2 + [GAD] + [euler_2nd]."""
+    return 2 + (params.riemann_scheme == "GAD") + (params.projection_scheme == "euler_2nd")
+
+
+def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=False,
+                out_range=None, dt_accumulate=False, swap=True):
     """One directional sweep as a single kernel launch (armon_hip_sweep). The halo cells of process
     boundaries must already hold the neighbour's (ρ,u,v,E). ``emit_dt``: also reduce the CFL time step
     of the resulting state into ``grid.dt_scalar`` (device)."""
@@ -344,9 +350,39 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=
         d.dt_cfl_out = grid.dt_scalar.ptr
         d.cfl_dx = params.domain_size[0] / params.global_grid[0]
         d.cfl_dy = params.domain_size[1] / params.global_grid[1]
+        d.dt_accumulate = int(dt_accumulate)
         grid.dt_pending = True
+    if out_range is not None:
+        d.out_lo, d.out_hi = out_range
     with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
         check(_L().armon_hip_sweep(params.device.ctx, C.byref(d)))
+    if swap:
+        grid.swap_state()
+
+
+def fused_sweep_overlapped(params, grid, axis, dt, dx, **emit):
+    """Fused sweep of a tile with process boundaries along ``axis``: the halo exchange of (ρ,u,v,E) runs while
+    the interior — the cells at least LAG away from the remote sides, which read no ghost cell — is computed;
+    the LAG-wide boundary strips follow once the ghosts are unpacked (ref src/solver.jl:58-285 gets the same
+    overlap from its async block state machine)."""
+    lag = sweep_lag(params)
+    n = params.N[int(axis) - 1]
+    lo_remote = params.neighbours[first_side(axis)] != PROC_NULL
+    hi_remote = params.neighbours[last_side(axis)] != PROC_NULL
+    comm = grid.comm
+    if not (lo_remote or hi_remote):
+        return fused_sweep(params, grid, axis, dt, dx, **emit)
+    if n < 2 * lag + 1 or not getattr(params, "overlap_halo", True):
+        comm.exchange(sides_along(axis), STATE_VARS)
+        return fused_sweep(params, grid, axis, dt, dx, **emit)
+    handle = comm.start(sides_along(axis), STATE_VARS)
+    lo, hi = (lag if lo_remote else 0), (n - lag if hi_remote else n)
+    fused_sweep(params, grid, axis, dt, dx, out_range=(lo, hi), swap=False, **emit)
+    comm.finish(handle)
+    if lo_remote:
+        fused_sweep(params, grid, axis, dt, dx, out_range=(0, lag), swap=False, dt_accumulate=True, **emit)
+    if hi_remote:
+        fused_sweep(params, grid, axis, dt, dx, out_range=(n - lag, n), swap=False, dt_accumulate=True, **emit)
     grid.swap_state()
 
 
@@ -380,15 +416,12 @@ def solver_cycle(params, grid, last_cycle=True):
         dx = params.domain_size[i_ax] / params.global_grid[i_ax]
         dt = gdt.current_dt * dt_factor
         if params.use_fused_sweep:
-            if params.use_MPI:
-                from .halo_exchange import exchange_state_halo
-                exchange_state_halo(params, grid, axis)
             # The last sweep of a cycle also reduces the next cycle's CFL step (post-sweep u, v with its
             # own pre-sweep c: what the reference's dtCFL_kernel reads) and, on the final
             # cycle, materialises the pre-sweep p that the reference leaves in memory.
             last = k == len(sweeps) - 1
-            fused_sweep(params, grid, axis, dt, dx, emit_p=last and last_cycle,
-                        emit_dt=last and not params.cst_dt)
+            sweep = fused_sweep_overlapped if params.use_MPI else fused_sweep
+            sweep(params, grid, axis, dt, dx, emit_p=last and last_cycle, emit_dt=last and not params.cst_dt)
         else:
             update_EOS(params, grid, axis)
             block_ghost_exchange(params, grid, axis)

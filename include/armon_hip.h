@@ -225,6 +225,14 @@ typedef struct {
      * device double, written by a follow-up fold kernel on the same stream). */
     double *dt_cfl_out;
     double  cfl_dx, cfl_dy;  /* GLOBAL cell sizes along x and y (ref src/reductions.jl:92)        */
+    /* Partial sweeps, for overlapping the halo exchange with compute: produce only the cells
+     * out_lo <= i < out_hi along the sweep axis (0-based real coordinates; out_hi == 0 means the whole
+     * block). The interior [LAG, n-LAG) needs no ghost cell and can run while the halos travel; the two
+     * LAG-wide boundary strips follow once the ghosts are in. dt_accumulate != 0: *dt_cfl_out =
+     * min(*dt_cfl_out, this launch's value) instead of overwriting it. */
+    int64_t out_lo, out_hi;
+    int32_t dt_accumulate;
+    int32_t reserved;
 } armon_sweep_desc;
 
 ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);

@@ -230,3 +230,36 @@ def test_alternative_x_kernels(oracle, test, N, opts, xk, exact):
         else:
             assert np.abs(a - b).max() <= 1e-11 * max(np.abs(b).max(), 1e-300), k
     assert (stats.last_dt == orun.last_dt) if exact else abs(stats.last_dt - orun.last_dt) <= 1e-12 * orun.last_dt
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+@pytest.mark.parametrize("axis_name", ["X", "Y"])
+@pytest.mark.parametrize("scheme,projection", [("GAD", "euler_2nd"), ("Godunov", "euler")])
+def test_partial_sweeps_equal_the_full_sweep(axis_name, scheme, projection, exact):
+    """interior [LAG, n-LAG) + the two LAG-wide strips == one full sweep, including the fused dt."""
+    import armon_amd
+    from armon_amd.blocking import Axis
+    from armon_amd.solver import BlockGrid, fused_sweep, init_test, sweep_lag
+    N = (150, 70)
+    axis = Axis.X if axis_name == "X" else Axis.Y
+    n = N[int(axis) - 1]
+    res = []
+    for split in (False, True):
+        params = armon_amd.ArmonParameters(test="Sod_circ", N=N, scheme=scheme, projection=projection, silent=5,
+                                           exact_arithmetic=exact)
+        grid = BlockGrid(params)
+        init_test(params, grid)
+        lag = sweep_lag(params)
+        dx, dt = 1.0 / n, 0.2 / n
+        if not split:
+            fused_sweep(params, grid, axis, dt, dx, emit_dt=True, emit_p=True)
+        else:
+            fused_sweep(params, grid, axis, dt, dx, emit_dt=True, emit_p=True, out_range=(lag, n - lag), swap=False)
+            fused_sweep(params, grid, axis, dt, dx, emit_dt=True, emit_p=True, out_range=(0, lag), swap=False, dt_accumulate=True)
+            fused_sweep(params, grid, axis, dt, dx, emit_dt=True, emit_p=True, out_range=(n - lag, n), swap=False, dt_accumulate=True)
+            grid.swap_state()
+        host = grid.device_to_host(("rho", "u", "v", "E", "p"))
+        res.append(({k: grid.real_view(v).copy() for k, v in host.items()}, float(grid.dt_scalar.to_host()[0])))
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    assert res[0][1] == res[1][1] and np.isfinite(res[0][1])
