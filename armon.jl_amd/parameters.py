@@ -189,8 +189,8 @@ class ArmonParameters:
                      write_ghosts=False, write_slices=False, output_precision=None, animation_step=0,
                      compare=False, is_ref=False, comparison_tolerance=1e-10, check_result=False,
                      return_data=False, **options):
-        if compare or is_ref:
-            solver_error("config", "step-by-step comparison files (compare/is_ref) are not implemented")
+        self.compare, self.is_ref = bool(compare), bool(is_ref)
+        self.comparison_tolerance = float(comparison_tolerance)
         self.silent = silent
         self.output_dir, self.output_file = output_dir, output_file
         self.write_output, self.write_ghosts = write_output, write_ghosts
@@ -215,7 +215,8 @@ class ArmonParameters:
         self.device_id = int(device_id)
         self._stream = stream
         self._device = None     # created on first use, so that configuration errors need no GPU
-        self.use_fused_sweep = bool(use_fused_sweep)
+        # per-step dumps / comparisons need the intermediate states: only the staged path has them
+        self.use_fused_sweep = bool(use_fused_sweep) and not self.compare
         self.exact_arithmetic = bool(exact_arithmetic)
         self.backend_options = dict(device_id=device_id, use_fused_sweep=self.use_fused_sweep,
                                     exact_arithmetic=self.exact_arithmetic)

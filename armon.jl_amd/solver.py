@@ -402,13 +402,28 @@ def next_time_step(params, grid):
     gdt.update_dt(global_min(params, local_dt))
 
 
+def _checkpoint(params, grid, label, axis=Axis.X):
+    """ref @checkpoint, src/solver.jl:40-55 → src/io.jl:185-227 (compare / is_ref options)"""
+    if not params.compare:
+        return False
+    from .io import step_checkpoint
+    return step_checkpoint(params, grid, label, axis.name)
+
+
 def solver_cycle(params, grid, last_cycle=True):
-    """ref src/solver.jl:288-320. ``last_cycle`` (fused path only): materialise p (the reference's
-    saved_vars hold the EOS of the state before the last sweep) after this cycle."""
+    """ref src/solver.jl:288-320 — returns True when a step comparison (``compare``) found a difference.
+    ``last_cycle`` (fused path only): materialise p (the reference's saved_vars hold the EOS of the state
+    before the last sweep) after this cycle."""
     gdt = grid.global_dt
     if gdt.cycle == 0 and not grid.dt_pending:
+        if _checkpoint(params, grid, "init_test"):
+            return True
         update_EOS(params, grid)
+        if _checkpoint(params, grid, "EOS_init"):
+            return True
     next_time_step(params, grid)
+    if _checkpoint(params, grid, "time_step"):
+        return True
     sweeps = split_axes(params.axis_splitting, gdt.cycle)
     for k, (axis, dt_factor) in enumerate(sweeps):
         # update_solver_state!: ref src/solver_state.jl:339-345
@@ -424,10 +439,21 @@ def solver_cycle(params, grid, last_cycle=True):
             sweep(params, grid, axis, dt, dx, emit_p=last and last_cycle, emit_dt=last and not params.cst_dt)
         else:
             update_EOS(params, grid, axis)
+            if _checkpoint(params, grid, "EOS", axis):
+                return True
             block_ghost_exchange(params, grid, axis)
+            if _checkpoint(params, grid, "boundary_conditions", axis):
+                return True
             numerical_fluxes(params, grid, axis, dt, dx)
+            if _checkpoint(params, grid, "numerical_fluxes", axis):
+                return True
             cell_update(params, grid, axis, dt, dx)
+            if _checkpoint(params, grid, "cell_update", axis):
+                return True
             projection_remap(params, grid, axis, dt, dx)
+            if _checkpoint(params, grid, "projection_remap", axis):
+                return True
+    return False
 
 
 def time_loop(params, grid):
@@ -444,7 +470,8 @@ def time_loop(params, grid):
             # the cycle's dt is only known after next_time_step on cycle 0: be conservative there
             ends = (gdt.cycle + 1 >= params.maxcycle or gdt.current_dt == 0
                     or gdt.time + gdt.current_dt >= params.maxtime)
-        solver_cycle(params, grid, last_cycle=ends)
+        if solver_cycle(params, grid, last_cycle=ends):
+            break
         gdt.next_cycle()
         if params.silent <= 1:
             params.wait()

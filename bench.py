@@ -124,7 +124,7 @@ def main():
         args.gpus = world
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ARMON_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise RCCL init/all-reduce with one rank
         import torch
         import torch.distributed as dist
         # Rehearsal knob (one-GPU box): ARMON_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo with host
@@ -146,10 +146,10 @@ def main():
     params = armon_amd.ArmonParameters(
         test=args.test, N=N_global, scheme=args.scheme, riemann_limiter="minmod", projection="euler_2nd",
         axis_splitting="Sequential", nghost=4, maxtime=1e9, maxcycle=10 ** 9, silent=5,
-        use_MPI=world > 1, P=P, device_id=local_rank,
+        use_MPI=dist is not None, P=P, device_id=local_rank,
         use_fused_sweep=not args.staged, exact_arithmetic=args.exact)
     grid = BlockGrid(params)
-    if world > 1:
+    if dist is not None:
         from armon_amd.halo_exchange import setup
         setup(params, grid)
     init_test(params, grid)

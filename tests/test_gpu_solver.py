@@ -263,3 +263,34 @@ def test_partial_sweeps_equal_the_full_sweep(axis_name, scheme, projection, exac
     for k in res[0][0]:
         assert np.array_equal(res[0][0][k], res[1][0][k]), k
     assert res[0][1] == res[1][1] and np.isfinite(res[0][1])
+
+
+def test_step_checkpoints_dump_then_compare(tmp_path):
+    """compare / is_ref (ref src/io.jl:185-227, src/solver.jl:288-320): dump every sub-step, re-run against the
+    dumps, then detect a deliberate change at the first sub-step it affects."""
+    import armon_amd
+    common = dict(test="Sod_circ", N=(24, 20), maxcycle=3, silent=5, output_dir=str(tmp_path), output_file="chk",
+                  compare=True)
+    ref = armon_amd.armon(armon_amd.ArmonParameters(is_ref=True, **common))
+    assert ref.cycles == 3
+    names = sorted(p.name for p in tmp_path.iterdir())
+    for expected in ("chk_000_init_test_X", "chk_000_EOS_init_X", "chk_000_time_step_X", "chk_000_EOS_X",
+                     "chk_000_boundary_conditions_X", "chk_000_numerical_fluxes_X", "chk_000_cell_update_X",
+                     "chk_000_projection_remap_Y", "chk_002_projection_remap_Y"):
+        assert expected in names, expected
+    same = armon_amd.armon(armon_amd.ArmonParameters(is_ref=False, **common))
+    assert same.cycles == 3 and not any(n.endswith("_diff") for n in (p.name for p in tmp_path.iterdir()))
+    other = armon_amd.armon(armon_amd.ArmonParameters(is_ref=False, cfl=0.5, **common))
+    assert other.cycles == 0                                      # stopped at cycle 0's time step comparison
+    
+
+def test_write_output_in_reference_format(tmp_path):
+    import armon_amd
+    from armon_amd import io as aio
+    params = armon_amd.ArmonParameters(test="Sod", N=(100, 100), maxcycle=1000, silent=5, write_output=True,
+                                       output_dir=str(tmp_path), output_file="sod", return_data=True, exact_arithmetic=True)
+    stats = armon_amd.armon(params)
+    g = load_golden("Sod")
+    host = aio.read_sub_domain_file(params, "sod")
+    for k in ("x", "y", "rho", "u", "v", "p"):
+        assert isapprox_count(stats.data.real_view(host[k]), g[k]) == 0, k

@@ -216,3 +216,46 @@ def test_cartesian_grid_and_neighbours():
 
 def test_memory_required():
     assert armon_amd.memory_required((16384, 16384), 4) == 20 * 16392 * 16392 * 8
+
+
+# ---- text I/O in the reference's format (ref src/io.jl) -----------------------------------------------------
+def test_output_format_roundtrip_and_reference_line(tmp_path):
+    import io as _io
+    from armon_amd import io as aio
+    from conftest import load_golden
+    g = load_golden("Sod")
+    p = ArmonParameters(test="Sod", N=(100, 100), output_dir=str(tmp_path))
+    n = p.block_size.n_cells
+    sx = p.block_size.size[0]
+    host = {}
+    for k in aio.SAVED_VARS:
+        a = np.full((sx, sx), -7.0)
+        a[4:104, 4:104] = g[k]
+        host[k] = a.ravel()
+    buf = _io.StringIO()
+    aio.write_blocks_to_file(p, host, buf)
+    lines = buf.getvalue().split("\n")
+    # first cell of the reference's golden file, character for character (ref test/reference_data/ref_Sod_64bits.csv:2)
+    assert lines[0] == (" 0.00000000000000000e+00,  0.00000000000000000e+00,  1.00000000000000000e+00,"
+                        "  0.00000000000000000e+00,  0.00000000000000000e+00,  9.99999999999999778e-01")
+    assert sum(1 for l in lines if l.strip()) == 100 * 100 and lines[100] == ""      # blank line between rows
+    back = {k: np.full(n, np.nan) for k in aio.SAVED_VARS}
+    aio.read_data_from_file(p, back, _io.StringIO(buf.getvalue()))
+    for k in aio.SAVED_VARS:      # 17 significant digits round-trip fp64 exactly
+        assert np.array_equal(np.asarray(back[k]).reshape(sx, sx)[4:104, 4:104], g[k])
+    # golden-file reader (header + cells)
+    path = tmp_path / "ref.csv"
+    with open(path, "w") as f:
+        f.write("%#.15g, %d\n" % (float(g["dt"]), int(g["cycles"])))
+        f.write(buf.getvalue())
+    dt, cycles, vals = aio.read_reference_file(str(path), (100, 100))
+    assert cycles == 45 and abs(dt - float(g["dt"])) < 1e-17 and np.array_equal(vals["rho"], g["rho"])
+
+
+def test_file_paths_and_time_step_file(tmp_path):
+    from armon_amd import io as aio
+    p = ArmonParameters(test="Sod", N=(8, 8), output_dir=str(tmp_path / "out"), output_file="run")
+    assert aio.build_file_path(p, "run_003_EOS_X") == str(tmp_path / "out" / "run_003_EOS_X")
+    aio.write_time_step_file(p, 0.00431962688696710, "dt")
+    assert open(tmp_path / "out" / "dt").read() == " 4.31962688696709961e-03\n"      # %#24.17e
+    assert aio.read_time_step_file(p, "dt") == 0.00431962688696710
