@@ -40,28 +40,39 @@ class BlockData(C.Structure):
     _fields_ = [(f, C.c_void_p) for f in FIELDS]
 
 
-class Run(C.Structure):
-    _fields_ = [("test", C.c_int32), ("scheme", C.c_int32), ("limiter", C.c_int32),
-                ("projection", C.c_int32), ("splitting", C.c_int32), ("nghost", C.c_int32),
-                ("nx", C.c_int64), ("ny", C.c_int64),
-                ("domain_size", C.c_double * 2), ("origin", C.c_double * 2),
-                ("cfl", C.c_double), ("maxtime", C.c_double), ("maxcycle", C.c_int64),
-                ("cst_dt", C.c_int32), ("Dt", C.c_double),
-                ("final_time", C.c_double), ("last_dt", C.c_double), ("cycles", C.c_int64),
-                ("solve_seconds", C.c_double),
-                ("initial_mass", C.c_double), ("initial_energy", C.c_double),
-                ("final_mass", C.c_double), ("final_energy", C.c_double),
-                ("status", C.c_int32)]
+def _run_struct(real):
+    class _Run(C.Structure):
+        _fields_ = [("test", C.c_int32), ("scheme", C.c_int32), ("limiter", C.c_int32),
+                    ("projection", C.c_int32), ("splitting", C.c_int32), ("nghost", C.c_int32),
+                    ("nx", C.c_int64), ("ny", C.c_int64),
+                    ("domain_size", real * 2), ("origin", real * 2),
+                    ("cfl", real), ("maxtime", real), ("maxcycle", C.c_int64),
+                    ("cst_dt", C.c_int32), ("Dt", real),
+                    ("final_time", real), ("last_dt", real), ("cycles", C.c_int64),
+                    ("solve_seconds", C.c_double),
+                    ("initial_mass", real), ("initial_energy", real),
+                    ("final_mass", real), ("final_energy", real),
+                    ("status", C.c_int32)]
+    return _Run
 
 
-def build(native=False, force=False):
-    """Compile the oracle with gcc (seconds). ``native`` → -march=native into its own file."""
+Run = _run_struct(C.c_double)
+Run32 = _run_struct(C.c_float)
+
+
+def build(native=False, force=False, f32=False):
+    """Compile the oracle with gcc (seconds). ``native`` → -march=native into its own file; ``f32`` → the
+    fp32 build of the same source (libarmon_oracle_f32.so)."""
     out = "libarmon_oracle_native.so" if native else "libarmon_oracle.so"
+    if f32:
+        out = "libarmon_oracle_f32.so"
     path = os.path.join(_HERE, out)
     src = os.path.join(_HERE, "armon_oracle.c")
     if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        args = ["make", "-C", _HERE, "-B", f"OUT={out}"]
-        if native:
+        args = ["make", "-C", _HERE, "-B", out if f32 else f"OUT={out}"]
+        if f32:
+            args = ["make", "-C", _HERE, "-B", "libarmon_oracle_f32.so"]
+        elif native:
             args.append("ARCH=native")
         subprocess.run(args, check=True, capture_output=True)
     return path
@@ -70,10 +81,13 @@ def build(native=False, force=False):
 _libs = {}
 
 
-def lib(native=False):
-    if native not in _libs:
-        L = C.CDLL(build(native))
-        dp, i64, dbl, ci = C.c_void_p, C.c_int64, C.c_double, C.c_int
+def lib(native=False, f32=False):
+    key = (native, f32)
+    if key not in _libs:
+        L = C.CDLL(build(native, f32=f32))
+        dp, i64, ci = C.c_void_p, C.c_int64, C.c_int
+        dbl = C.c_float if f32 else C.c_double
+        RunT = Run32 if f32 else Run
         L.armon_oracle_set_threads.argtypes = [ci]
         L.armon_oracle_get_threads.restype = ci
         L.armon_oracle_perfect_gas_EOS.argtypes = [Range, dbl] + [dp] * 7
@@ -93,14 +107,14 @@ def lib(native=False):
         L.armon_oracle_init_test.argtypes = [Range, ci, i64, i64, ci, C.POINTER(i64 * 2),
                                              C.POINTER(i64 * 2), C.POINTER(dbl * 2),
                                              C.POINTER(dbl * 2), dbl, C.POINTER(BlockData)]
-        L.armon_oracle_solve.argtypes = [C.POINTER(Run), C.POINTER(BlockData), ci]
+        L.armon_oracle_solve.argtypes = [C.POINTER(RunT), C.POINTER(BlockData), ci]
         L.armon_oracle_solve.restype = ci
-        _libs[native] = L
-    return _libs[native]
+        _libs[key] = L
+    return _libs[key]
 
 
 def ptr(a):
-    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    assert a.dtype in (np.float64, np.float32) and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 
 
@@ -112,9 +126,9 @@ def domain_range(nx, ny, g, bl=(0, 0), tr=(0, 0)):
     return Range((fy + g - 1) * row, row, ly - fy + 1, fx + g - 1, lx - fx + 1)
 
 
-def alloc_fields(nx, ny, g, fill=0.0):
+def alloc_fields(nx, ny, g, fill=0.0, dtype=np.float64):
     n = (nx + 2 * g) * (ny + 2 * g)
-    return {f: np.full(n, fill, dtype=np.float64) for f in FIELDS}
+    return {f: np.full(n, fill, dtype=dtype) for f in FIELDS}
 
 
 def block_data(fields):
@@ -127,13 +141,14 @@ def block_data(fields):
 def solve(test="Sod", N=(100, 100), scheme="GAD", riemann_limiter="minmod", projection="euler_2nd",
           axis_splitting="Sequential", nghost=4, cfl=0., maxtime=0., maxcycle=500_000,
           cst_dt=False, Dt=0., domain_size=None, origin=None, threads=1, native=False,
-          fields=None, skip_init=False):
+          fields=None, skip_init=False, data_type=np.float64):
     """Run the oracle's armon(): returns (Run, fields dict). Option names follow ArmonParameters."""
-    L = lib(native)
+    f32 = np.dtype(data_type) == np.float32
+    L = lib(native, f32=f32)
     L.armon_oracle_set_threads(threads)
     nx, ny = N
     d = DEFAULTS[test]
-    run = Run()
+    run = Run32() if f32 else Run()
     run.test, run.scheme, run.limiter = TESTS[test], SCHEMES[scheme], LIMITERS[riemann_limiter]
     run.projection, run.splitting, run.nghost = PROJECTIONS[projection], SPLITTINGS[axis_splitting], nghost
     run.nx, run.ny = nx, ny
@@ -146,7 +161,7 @@ def solve(test="Sod", N=(100, 100), scheme="GAD", riemann_limiter="minmod", proj
     run.maxcycle = maxcycle
     run.cst_dt, run.Dt = int(cst_dt), Dt
     if fields is None:
-        fields = alloc_fields(nx, ny, nghost)
+        fields = alloc_fields(nx, ny, nghost, dtype=np.float32 if f32 else np.float64)
     bd = block_data(fields)
     L.armon_oracle_solve(C.byref(run), C.byref(bd), int(skip_init))
     return run, fields
