@@ -103,6 +103,30 @@ SIGNATURES = {
 }
 
 
+def _add_f32_signatures():
+    """Every kernel entry point also exists with an `_f32` suffix: float arrays and scalars."""
+    flt = C.c_float
+    for name in ("perfect_gas_EOS", "bizarrium_EOS", "acoustic", "acoustic_GAD", "cell_update",
+                 "advection_first_order", "advection_second_order", "euler_projection", "boundary_conditions",
+                 "pack_to_array", "unpack_from_array", "dtCFL_async", "dtCFL", "conservation_vars", "init_test"):
+        res, args = SIGNATURES["armon_hip_" + name]
+        conv = []
+        for a in args:
+            if a is _dbl:
+                conv.append(flt)
+            elif a is C.POINTER(_dbl):
+                conv.append(C.POINTER(flt))
+            elif a is C.POINTER(_dbl * 2):
+                conv.append(C.POINTER(flt * 2))
+            else:
+                conv.append(a)
+        SIGNATURES["armon_hip_" + name + "_f32"] = (res, conv)
+    SIGNATURES["armon_hip_sweep_f32"] = SIGNATURES["armon_hip_sweep"]
+
+
+_add_f32_signatures()
+
+
 def lib():
     """Load libarmon_hip.so (once) and declare every entry point. Raises if it is not built."""
     global _lib

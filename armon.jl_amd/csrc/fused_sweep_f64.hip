@@ -1,0 +1,5 @@
+// fused_sweep_f64.hip — fp64 instantiation of the fused sweep (armon_hip_sweep).
+#define ARMON_SWEEP_REAL double
+#define ARMON_SWEEP_FN armon_hip_sweep
+#define ARMON_SWEEP_DESC armon_sweep_desc
+#include "fused_sweep_impl.hpp"

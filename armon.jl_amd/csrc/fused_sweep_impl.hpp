@@ -14,6 +14,7 @@
 //    transposes 64-row × 8-column tiles through LDS and each lane marches along its row with the same
 //    pipeline as the Y sweep.
 // Redundant work is confined to the LAG (≤4) cells at both ends of a run / strip.
+#pragma once
 #include "common.hpp"
 #include "reduce.hpp"
 #include "sweep_pipeline.hpp"
@@ -25,7 +26,16 @@
 
 using namespace armon;
 
+// This file is compiled twice: fused_sweep_f64.hip (real = real, armon_hip_sweep) and fused_sweep_f32.hip
+// (real = float, armon_hip_sweep_f32); everything else lives in the translation unit's anonymous namespace.
+#ifndef ARMON_SWEEP_REAL
+#error "include through fused_sweep_f64.hip / fused_sweep_f32.hip"
+#endif
+
 namespace {
+
+using real = ARMON_SWEEP_REAL;
+using vec2 = std::conditional<std::is_same<real, double>::value, double2, float2>::type;
 
 struct sweep_args {
     int64_t nx, ny, row_len;       // real cells and array pitch (nx + 2g)
@@ -35,21 +45,21 @@ struct sweep_args {
     int32_t seg;                   // cells per run along the sweep axis (marching kernels)
     int32_t x_kernel;              // X sweep form: 0 spatial K=2, 3 spatial K=1, 2 LDS-transposed march
     int64_t o_lo, o_hi;            // cells to produce along the sweep axis: [o_lo, o_hi)
-    double dt, dx, gamma;
-    double fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
-    const double *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
-    double *rho_out, *ua_out, *ut_out, *E_out;
-    double *p_out, *c_out;
-    double* partials;              // dt/CFL tracking: [2 * n_blocks] (max |u|±c, max |v|±c per workgroup)
+    real dt, dx, gamma;
+    real fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
+    const real *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
+    real *rho_out, *ua_out, *ut_out, *E_out;
+    real *p_out, *c_out;
+    real* partials;              // dt/CFL tracking: [2 * n_blocks] (max |u|±c, max |v|±c per workgroup)
 };
 
 // Source index and velocity factors of cell `j` (0-based real coordinate along the sweep axis, may be
 // a ghost): physical boundaries mirror the inside (ref src/halo_exchange.jl:2-29), process boundaries
 // read the ghost cells filled by the halo exchange.
-__device__ __forceinline__ int64_t bc_source(const sweep_args& a, int64_t n, int64_t j, double& fa, double& ft)
+__device__ __forceinline__ int64_t bc_source(const sweep_args& a, int64_t n, int64_t j, real& fa, real& ft)
 {
-    fa = 1.;
-    ft = 1.;
+    fa = 1;
+    ft = 1;
     if (j < 0 && a.bc_low) {
         fa = a.fa_low;
         ft = a.ft_low;
@@ -78,34 +88,45 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
 }
-__device__ __forceinline__ double buf_load(rsrc_t r, unsigned voff, unsigned soff)
+template <typename T> __device__ __forceinline__ T buf_load(rsrc_t r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ double buf_load<double>(rsrc_t r, unsigned voff, unsigned soff)
 {
     const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return __builtin_bit_cast(double, v);
 }
+template <>
+__device__ __forceinline__ float buf_load<float>(rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff, double x)
 {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff, float x)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, voff, soff, 0);
 }
 
 // dt/CFL tracking (ref src/reductions.jl:13-20). The reference takes min over cells of
 // min(dx/|max(|u+c|,|u-c|)|, dy/|max(|v+c|,|v-c|)|); IEEE division is monotonic, so that minimum equals
 // min(dx / max_cells(..u..), dy / max_cells(..v..)) bit for bit: track the two maxima, divide once.
 struct cfl_track {
-    double au = 0., av = 0.;
-    __device__ __forceinline__ void add(double u, double v, double c)
+    real au = 0, av = 0;
+    __device__ __forceinline__ void add(real u, real v, real c)
     {
-        au = phys::mx(au, fabs(phys::mx(fabs(u + c), fabs(u - c))));
-        av = phys::mx(av, fabs(phys::mx(fabs(v + c), fabs(v - c))));
+        au = phys::mx(au, phys::abs_(phys::mx(phys::abs_(u + c), phys::abs_(u - c))));
+        av = phys::mx(av, phys::abs_(phys::mx(phys::abs_(v + c), phys::abs_(v - c))));
     }
 };
 
 template <int NWAVES>
-__device__ __forceinline__ void cfl_block_store(const cfl_track& t, double* partials, int64_t block, int tid)
+__device__ __forceinline__ void cfl_block_store(const cfl_track& t, real* partials, int64_t block, int tid)
 {
-    __shared__ double lds[NWAVES];
-    const double au = red::block_reduce<red::op_max, NWAVES>(t.au, lds, tid);
-    const double av = red::block_reduce<red::op_max, NWAVES>(t.av, lds, tid);
+    __shared__ real lds[NWAVES];
+    const real au = red::block_reduce<red::op_max, NWAVES>(t.au, lds, tid);
+    const real av = red::block_reduce<red::op_max, NWAVES>(t.av, lds, tid);
     if (tid == 0) {
         partials[2 * block] = au;
         partials[2 * block + 1] = av;
@@ -113,11 +134,11 @@ __device__ __forceinline__ void cfl_block_store(const cfl_track& t, double* part
 }
 
 __global__ void __launch_bounds__(256)
-k_fold_dt(const double* __restrict__ partials, int64_t n_blocks, double dx, double dy, double* __restrict__ out,
+k_fold_dt(const real* __restrict__ partials, int64_t n_blocks, real dx, real dy, real* __restrict__ out,
           int accumulate)
 {
-    __shared__ double lds[4];
-    double au = 0., av = 0.;
+    __shared__ real lds[4];
+    real au = 0, av = 0;
     for (int64_t k = threadIdx.x; k < n_blocks; k += blockDim.x) {
         au = phys::mx(au, partials[2 * k]);
         av = phys::mx(av, partials[2 * k + 1]);
@@ -125,7 +146,7 @@ k_fold_dt(const double* __restrict__ partials, int64_t n_blocks, double dx, doub
     au = red::block_reduce<red::op_max, 4>(au, lds, threadIdx.x);
     av = red::block_reduce<red::op_max, 4>(av, lds, threadIdx.x);
     if (threadIdx.x == 0) {
-        const double dt = phys::mn(dx / au, dy / av);
+        const real dt = phys::mn(dx / au, dy / av);
         out[0] = accumulate ? phys::mn(out[0], dt) : dt;
     }
 }
@@ -156,8 +177,8 @@ k_sweep_y(sweep_args a)
 
     // Descriptors are based at the first row this run touches, so every scalar row offset is a small
     // non-negative 32-bit number whatever the size of the arrays (mirrored rows lie inside the run).
-    const unsigned colb = (unsigned)(x + g) * 8u;
-    const unsigned pitchb = (unsigned)a.row_len * 8u;
+    const unsigned colb = (unsigned)(x + g) * (unsigned)sizeof(real);
+    const unsigned pitchb = (unsigned)a.row_len * (unsigned)sizeof(real);
     const int64_t in_base = (int64_t)(jb + g) * a.row_len, out_base = (int64_t)(o0 + g) * a.row_len;
     const rsrc_t r_rho = make_rsrc(a.rho_in + in_base), r_ua = make_rsrc(a.ua_in + in_base);
     const rsrc_t r_ut = make_rsrc(a.ut_in + in_base), r_E = make_rsrc(a.E_in + in_base);
@@ -183,21 +204,21 @@ k_sweep_y(sweep_args a)
             // physical boundary: mirror of the inside (ref src/halo_exchange.jl:2-29)
             const int src = m_lo ? -1 - lj : (m_hi ? 2 * ny - 1 - lj : lj);
             const unsigned off = (unsigned)(src - jb) * pitchb;
-            const double fa = m_lo ? a.fa_low : (m_hi ? a.fa_high : 1.);
-            const double ft = m_lo ? a.ft_low : (m_hi ? a.ft_high : 1.);
-            dst.rho = buf_load(r_rho, colb, off);
-            dst.ua = buf_load(r_ua, colb, off) * fa;
-            dst.ut = buf_load(r_ut, colb, off) * ft;
-            dst.E = buf_load(r_E, colb, off);
+            const real fa = m_lo ? a.fa_low : (m_hi ? a.fa_high : real(1));
+            const real ft = m_lo ? a.ft_low : (m_hi ? a.ft_high : real(1));
+            dst.rho = buf_load<real>(r_rho, colb, off);
+            dst.ua = buf_load<real>(r_ua, colb, off) * fa;
+            dst.ut = buf_load<real>(r_ut, colb, off) * ft;
+            dst.E = buf_load<real>(r_E, colb, off);
             if (lj + 1 < je) {       // stay on the last row once the run is exhausted (padding steps)
                 lj++;
                 lo_off += pitchb;
             }
         } else {
-            dst.rho = buf_load(r_rho, colb, lo_off);
-            dst.ua = buf_load(r_ua, colb, lo_off);
-            dst.ut = buf_load(r_ut, colb, lo_off);
-            dst.E = buf_load(r_E, colb, lo_off);
+            dst.rho = buf_load<real>(r_rho, colb, lo_off);
+            dst.ua = buf_load<real>(r_ua, colb, lo_off);
+            dst.ut = buf_load<real>(r_ut, colb, lo_off);
+            dst.E = buf_load<real>(r_E, colb, lo_off);
             lj++;
             lo_off += pitchb;
         }
@@ -207,8 +228,8 @@ k_sweep_y(sweep_args a)
         constexpr int PH8 = decltype(ph)::value;
         constexpr bool CHECKED = decltype(checked)::value;
         load(integral_constant<int, PH8 + PF>{}, checked);   // row j + PF → slot (j + PF) mod 8
-        double p, c, c_lag;
-        const fused::Out4 out = pipe.template advance<true, PH8>(p, c, c_lag);
+        real p, c, c_lag;
+        const fused::Out4<real> out = pipe.template advance<true, PH8>(p, c, c_lag);
         const int o = j - LAG;
         if (CHECKED) {
             if (a.emit && j >= o0 && j < o1 && active) {
@@ -259,8 +280,8 @@ template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
 __global__ void __launch_bounds__(64 * kXSRows)
 k_sweep_x_dpp(sweep_args a, int niter)
 {
-    using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, K>;
-    using St = fused::Strip<K>;
+    using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, K, real>;
+    using St = fused::Strip<K, real>;
     constexpr int LAG = SW::LAG;
     constexpr int HALO = (K == 1) ? LAG : ((LAG + 1) & ~1);   // even for K = 2: strips stay pair-aligned
     constexpr int WIDTH = 64 * K;
@@ -271,15 +292,15 @@ k_sweep_x_dpp(sweep_args a, int niter)
     const bool row_ok = row_r < a.ny;                         // whole wave
     const int64_t row = row_ok ? row_r : a.ny - 1;
     const int64_t row_off = (row + a.g) * a.row_len + a.g;
-    const double* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
-    double* out[4] = {a.rho_out + row_off, a.ua_out + row_off, a.ut_out + row_off, a.E_out + row_off};
+    const real* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
+    real* out[4] = {a.rho_out + row_off, a.ua_out + row_off, a.ut_out + row_off, a.E_out + row_off};
     const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && (a.g % 2 == 0) && (a.o_lo % 2 == 0);   // uniform
 
     SW sw{a.dt, a.dx, a.gamma};
     cfl_track cfl;
 
     const int64_t w_first = a.o_lo + (int64_t)blockIdx.x * niter * STRIDE;
-    // Strips are double-buffered in registers: the loads of strip it+1 are issued before strip it is
+    // Strips are real-buffered in registers: the loads of strip it+1 are issued before strip it is
     // computed (the loop is unrolled by the two buffers, so no loaded register is ever copied).
     St buf[2][4];
     auto load_strip = [&](auto slot, int it) {
@@ -293,10 +314,10 @@ k_sweep_x_dpp(sweep_args a, int niter)
         const bool interior = cb >= 0 && cb + WIDTH <= a.nx;          // uniform: no ghost, no clamping
         if (interior && (K == 1 || vec_ok)) {
             if (K == 2) {
-                const double2 r = *reinterpret_cast<const double2*>(in[0] + j0);
-                const double2 u = *reinterpret_cast<const double2*>(in[1] + j0);
-                const double2 v = *reinterpret_cast<const double2*>(in[2] + j0);
-                const double2 e = *reinterpret_cast<const double2*>(in[3] + j0);
+                const vec2 r = *reinterpret_cast<const vec2*>(in[0] + j0);
+                const vec2 u = *reinterpret_cast<const vec2*>(in[1] + j0);
+                const vec2 v = *reinterpret_cast<const vec2*>(in[2] + j0);
+                const vec2 e = *reinterpret_cast<const vec2*>(in[3] + j0);
                 rho.v[0] = r.x; rho.v[K - 1] = r.y;
                 ua.v[0] = u.x; ua.v[K - 1] = u.y;
                 ut.v[0] = v.x; ut.v[K - 1] = v.y;
@@ -310,7 +331,7 @@ k_sweep_x_dpp(sweep_args a, int niter)
                 // clamp into the block (ghosts included), then mirror physical boundaries
                 int64_t j = j0 + k;
                 j = j < -(int64_t)a.g ? -(int64_t)a.g : (j > a.nx + a.g - 1 ? a.nx + a.g - 1 : j);
-                double fa, ft;
+                real fa, ft;
                 const int64_t src = bc_source(a, a.nx, j, fa, ft);
                 rho.v[k] = in[0][src];
                 ua.v[k] = in[1][src] * fa;
@@ -332,13 +353,13 @@ k_sweep_x_dpp(sweep_args a, int niter)
         // cells this lane may store: inside the strip's valid window and inside the block
         const int64_t hi = (w0 + STRIDE < a.o_hi) ? w0 + STRIDE : a.o_hi;
         if (K == 2 && vec_ok && j0 >= w0 && j0 + 1 < hi) {
-            *reinterpret_cast<double2*>(out[0] + j0) = double2{o_rho.v[0], o_rho.v[K - 1]};
-            *reinterpret_cast<double2*>(out[1] + j0) = double2{o_u.v[0], o_u.v[K - 1]};
-            *reinterpret_cast<double2*>(out[2] + j0) = double2{o_v.v[0], o_v.v[K - 1]};
-            *reinterpret_cast<double2*>(out[3] + j0) = double2{o_E.v[0], o_E.v[K - 1]};
+            *reinterpret_cast<vec2*>(out[0] + j0) = vec2{o_rho.v[0], o_rho.v[K - 1]};
+            *reinterpret_cast<vec2*>(out[1] + j0) = vec2{o_u.v[0], o_u.v[K - 1]};
+            *reinterpret_cast<vec2*>(out[2] + j0) = vec2{o_v.v[0], o_v.v[K - 1]};
+            *reinterpret_cast<vec2*>(out[3] + j0) = vec2{o_E.v[0], o_E.v[K - 1]};
             if (a.emit) {
-                if (a.emit & 1) *reinterpret_cast<double2*>(a.p_out + row_off + j0) = double2{p.v[0], p.v[K - 1]};
-                if (a.emit & 2) *reinterpret_cast<double2*>(a.c_out + row_off + j0) = double2{cs.v[0], cs.v[K - 1]};
+                if (a.emit & 1) *reinterpret_cast<vec2*>(a.p_out + row_off + j0) = vec2{p.v[0], p.v[K - 1]};
+                if (a.emit & 2) *reinterpret_cast<vec2*>(a.c_out + row_off + j0) = vec2{cs.v[0], cs.v[K - 1]};
             }
             if (TRACK) {
                 cfl.add(o_u.v[0], o_v.v[0], cs.v[0]);
@@ -384,7 +405,7 @@ k_sweep_x_lds(sweep_args a)
     constexpr int LAG = PIPE::LAG;
     constexpr int PITCH = CH + 1;                 // odd pitch in doubles: conflict-free column walks
     constexpr int RPI = kXRows / CH;              // rows covered by one wave-wide row-segment access
-    extern __shared__ double tile[];              // [planes][64][PITCH], planes = 4 (+2 when emitting p, c)
+    extern __shared__ real tile[];              // [planes][64][PITCH], planes = 4 (+2 when emitting p, c)
 
     const int lane = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * kXRows;
@@ -395,7 +416,7 @@ k_sweep_x_lds(sweep_args a)
     const bool emit = a.emit != 0;
 
     const int sub_row = lane / CH, sub_col = lane % CH;   // row-segment phase: lane → (row in group, column)
-    auto T = [&](int plane, int r, int t) -> double& { return tile[(plane * kXRows + r) * PITCH + t]; };
+    auto T = [&](int plane, int r, int t) -> real& { return tile[(plane * kXRows + r) * PITCH + t]; };
 
     PIPE pipe(a.dt, a.dx, a.gamma);
     cfl_track cfl;
@@ -404,7 +425,7 @@ k_sweep_x_lds(sweep_args a)
         // -- load phase: 64 rows × CH columns, 8 B per lane, CH*8 B contiguous per row
         {
             const int64_t j = jb + sub_col;
-            double fa, ft;
+            real fa, ft;
             const int64_t src = bc_source(a, a.nx, j, fa, ft);
 #pragma unroll
             for (int k = 0; k < CH; k++) {
@@ -427,8 +448,8 @@ k_sweep_x_lds(sweep_args a)
                 constexpr int t = decltype(phc)::value;
                 const int64_t j = jb + t;
                 if (j < j_end) {
-                    double p, c, c_lag;
-                    const fused::Out4 out = pipe.template push<false, t>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c, c_lag);
+                    real p, c, c_lag;
+                    const fused::Out4<real> out = pipe.template push<false, t>(T(0, lane, t), T(1, lane, t), T(2, lane, t), T(3, lane, t), p, c, c_lag);
                     T(0, lane, t) = out.rho;
                     T(1, lane, t) = out.ua;
                     T(2, lane, t) = out.ut;
@@ -485,7 +506,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     if (a.x_kernel == 2) {
         dim3 grid((unsigned)((n_out + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
         *n_blocks = (int64_t)grid.x * grid.y;
-        const size_t lds = (size_t)(a.emit ? 6 : 4) * kXRows * (kXChunk + 1) * sizeof(double);
+        const size_t lds = (size_t)(a.emit ? 6 : 4) * kXRows * (kXChunk + 1) * sizeof(real);
         hipLaunchKernelGGL((k_sweep_x_lds<PIPE, kXChunk, TRACK>), grid, dim3(kXRows), lds, ctx->stream, a);
         return check_launch("sweep_x_lds");
     }
@@ -525,8 +546,8 @@ int dispatch_track(armon_ctx* ctx, const sweep_args& a, int axis, bool track, in
 template <int SCHEME, int LIM, int PROJ, int EOS>
 int dispatch_exact(armon_ctx* ctx, const sweep_args& a, int axis, bool exact, bool track, int64_t* nb)
 {
-    if (exact) return dispatch_track<fused::Pipe<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis, track, nb);
-    return dispatch_track<fused::PipeFast<SCHEME, LIM, PROJ, EOS>>(ctx, a, axis, track, nb);
+    if (exact) return dispatch_track<fused::Pipe<SCHEME, LIM, PROJ, EOS, real>>(ctx, a, axis, track, nb);
+    return dispatch_track<fused::PipeFast<SCHEME, LIM, PROJ, EOS, real>>(ctx, a, axis, track, nb);
 }
 
 template <int SCHEME, int LIM, int PROJ>
@@ -547,7 +568,7 @@ int dispatch_proj(armon_ctx* ctx, const sweep_args& a, int axis, int eos, int pr
 
 }  // namespace
 
-extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
+extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
 {
     ARMON_REQUIRE(ctx && d, "NULL argument");
     ARMON_REQUIRE(d->axis == ARMON_AXIS_X || d->axis == ARMON_AXIS_Y, "invalid axis %d", d->axis);
@@ -581,14 +602,14 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     a.bc_low = d->bc_low;
     a.bc_high = d->bc_high;
     a.emit = (d->p_out ? 1 : 0) | (d->c_out ? 2 : 0);
-    a.dt = d->dt;
-    a.dx = d->dx;
-    a.gamma = d->gamma;
+    a.dt = (real)d->dt;
+    a.dx = (real)d->dx;
+    a.gamma = (real)d->gamma;
     const bool X = d->axis == ARMON_AXIS_X;
-    a.fa_low = X ? d->u_factor_low : d->v_factor_low;
-    a.ft_low = X ? d->v_factor_low : d->u_factor_low;
-    a.fa_high = X ? d->u_factor_high : d->v_factor_high;
-    a.ft_high = X ? d->v_factor_high : d->u_factor_high;
+    a.fa_low = (real)(X ? d->u_factor_low : d->v_factor_low);
+    a.ft_low = (real)(X ? d->v_factor_low : d->u_factor_low);
+    a.fa_high = (real)(X ? d->u_factor_high : d->v_factor_high);
+    a.ft_high = (real)(X ? d->v_factor_high : d->u_factor_high);
     a.rho_in = d->rho_in;
     a.ua_in = X ? d->u_in : d->v_in;
     a.ut_in = X ? d->v_in : d->u_in;
@@ -614,7 +635,7 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));
         if (rc != ARMON_OK) return rc;
-        a.partials = ctx->partials;
+        a.partials = reinterpret_cast<real*>(ctx->partials);
     }
 
     int64_t n_blocks = 0;
@@ -634,6 +655,6 @@ extern "C" int armon_hip_sweep(armon_ctx* ctx, const armon_sweep_desc* d)
         }
     }
     if (rc != ARMON_OK || !track) return rc;
-    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, ctx->partials, n_blocks, d->cfl_dx, d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
+    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
     return check_launch("fold_dt");
 }

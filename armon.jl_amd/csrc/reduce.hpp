@@ -10,27 +10,27 @@ namespace red {
 
 constexpr int kWave = 64;
 
-struct op_min { __device__ static double id() { return INFINITY; } __device__ static double f(double a, double b) { return phys::mn(a, b); } };
-struct op_max { __device__ static double id() { return 0.; } __device__ static double f(double a, double b) { return phys::mx(a, b); } };
-struct op_sum { __device__ static double id() { return 0.; } __device__ static double f(double a, double b) { return a + b; } };
+struct op_min { template <typename T> __device__ static T id() { return T(INFINITY); } template <typename T> __device__ static T f(T a, T b) { return phys::mn(a, b); } };
+struct op_max { template <typename T> __device__ static T id() { return T(0.); } template <typename T> __device__ static T f(T a, T b) { return phys::mx(a, b); } };
+struct op_sum { template <typename T> __device__ static T id() { return T(0.); } template <typename T> __device__ static T f(T a, T b) { return a + b; } };
 
-template <typename OP>
-__device__ __forceinline__ double wave_reduce(double v)
+template <typename OP, typename T>
+__device__ __forceinline__ T wave_reduce(T v)
 {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v = OP::f(v, __shfl_down(v, off, kWave));
     return v;   // valid in lane 0
 }
 
-// Reduce across a workgroup of NWAVES waves; result valid in thread 0. `lds` holds NWAVES doubles.
-template <typename OP, int NWAVES>
-__device__ __forceinline__ double block_reduce(double v, double* lds, int tid)
+// Reduce across a workgroup of NWAVES waves; result valid in thread 0. `lds` holds NWAVES values.
+template <typename OP, int NWAVES, typename T>
+__device__ __forceinline__ T block_reduce(T v, T* lds, int tid)
 {
     const int lane = tid & (kWave - 1), wave = tid / kWave;
     v = wave_reduce<OP>(v);
     if (lane == 0) lds[wave] = v;
     __syncthreads();
-    double r = OP::id();
+    T r = OP::template id<T>();
     if (tid == 0) {
 #pragma unroll
         for (int w = 0; w < NWAVES; w++) r = OP::f(r, lds[w]);

@@ -17,20 +17,21 @@ using red::kWave;
 using red::op_min;
 using red::op_sum;
 
-template <typename OP>
-__device__ __forceinline__ double block_reduce(double v, double* lds)
+template <typename OP, typename T>
+__device__ __forceinline__ T block_reduce(T v, T* lds)
 {
     return red::block_reduce<OP, kBlock / kWave>(v, lds, threadIdx.x);
 }
 
 // ---- a11: dtCFL (ref src/reductions.jl:2-53) -------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_dtCFL_partial(armon_range r, double dx, double dy, const double* __restrict__ u,
-                const double* __restrict__ v, const double* __restrict__ c,
-                double* __restrict__ partials)
+k_dtCFL_partial(armon_range r, T dx, T dy, const T* __restrict__ u,
+                const T* __restrict__ v, const T* __restrict__ c,
+                T* __restrict__ partials)
 {
-    __shared__ double lds[kBlock / kWave];
-    double acc = INFINITY;
+    __shared__ T lds[kBlock / kWave];
+    T acc = T(INFINITY);
     for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
         const int64_t base = r.col_start + j * r.col_step + r.row_start;
         for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < r.row_len;
@@ -39,31 +40,32 @@ k_dtCFL_partial(armon_range r, double dx, double dy, const double* __restrict__ 
             acc = phys::mn(acc, phys::dt_cfl_cell(u[i], v[i], c[i], dx, dy));
         }
     }
-    double res = block_reduce<op_min>(acc, lds);
+    T res = block_reduce<op_min>(acc, lds);
     if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = res;
 }
 
-template <typename OP, int NOUT>
+template <typename OP, int NOUT, typename T>
 __global__ void __launch_bounds__(kBlock)
-k_fold(const double* __restrict__ partials, int64_t n, double scale, double* __restrict__ out)
+k_fold(const T* __restrict__ partials, int64_t n, T scale, T* __restrict__ out)
 {
-    __shared__ double lds[kBlock / kWave];
+    __shared__ T lds[kBlock / kWave];
 #pragma unroll
     for (int o = 0; o < NOUT; o++) {
-        double acc = OP::id();
+        T acc = OP::template id<T>();
         for (int64_t k = threadIdx.x; k < n; k += blockDim.x) acc = OP::f(acc, partials[o * n + k]);
-        double res = block_reduce<OP>(acc, lds);
+        T res = block_reduce<OP>(acc, lds);
         if (threadIdx.x == 0) out[o] = res * scale;
     }
 }
 
 // ---- a15: conservation_vars (ref src/reductions.jl:202-259) ----------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_conservation_partial(armon_range r, const double* __restrict__ rho, const double* __restrict__ E,
-                       double* __restrict__ partials, int64_t n_partials)
+k_conservation_partial(armon_range r, const T* __restrict__ rho, const T* __restrict__ E,
+                       T* __restrict__ partials, int64_t n_partials)
 {
-    __shared__ double lds[kBlock / kWave];
-    double mass = 0., energy = 0.;
+    __shared__ T lds[kBlock / kWave];
+    T mass = 0., energy = 0.;
     for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
         const int64_t base = r.col_start + j * r.col_step + r.row_start;
         for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < r.row_len;
@@ -73,8 +75,8 @@ k_conservation_partial(armon_range r, const double* __restrict__ rho, const doub
             energy += rho[i] * E[i];
         }
     }
-    double m = block_reduce<op_sum>(mass, lds);
-    double e = block_reduce<op_sum>(energy, lds);
+    T m = block_reduce<op_sum>(mass, lds);
+    T e = block_reduce<op_sum>(energy, lds);
     if (threadIdx.x == 0) {
         const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
         partials[b] = m;
@@ -97,10 +99,10 @@ inline void reduce_grid(const armon_ctx* ctx, const armon_range& r, dim3& grid)
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int armon_hip_dtCFL_async(armon_ctx* ctx, armon_range r, double dx, double dy, const double* u,
-                          const double* v, const double* c, double* result_dev)
+template <typename T>
+int dtCFL_async_impl(armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, const T* v, const T* c, T* result_dev)
 {
     ARMON_REQUIRE(ctx != nullptr, "ctx is NULL");
     ARMON_REQUIRE(range_ok(r) && !range_empty(r), "dtCFL needs a non-empty range");
@@ -110,27 +112,30 @@ int armon_hip_dtCFL_async(armon_ctx* ctx, armon_range r, double dx, double dy, c
     const int64_t n = (int64_t)grid.x * grid.y;
     int rc = ensure_partials(ctx, (size_t)n * 2);
     if (rc != ARMON_OK) return rc;
-    hipLaunchKernelGGL(k_dtCFL_partial, grid, dim3(kBlock), 0, ctx->stream, r, dx, dy, u, v, c, ctx->partials);
+    T* partials = reinterpret_cast<T*>(ctx->partials);
+    hipLaunchKernelGGL(k_dtCFL_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, dx, dy, u, v, c, partials);
     rc = check_launch("dtCFL_partial");
     if (rc != ARMON_OK) return rc;
-    hipLaunchKernelGGL((k_fold<op_min, 1>), dim3(1), dim3(kBlock), 0, ctx->stream, ctx->partials, n, 1.0, result_dev);
+    hipLaunchKernelGGL((k_fold<op_min, 1, T>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, n, T(1.0), result_dev);
     return check_launch("dtCFL_fold");
 }
 
-int armon_hip_dtCFL(armon_ctx* ctx, armon_range r, double dx, double dy, const double* u,
-                    const double* v, const double* c, double* result_host)
+template <typename T>
+int dtCFL_impl(armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, const T* v, const T* c, T* result_host)
 {
     ARMON_REQUIRE(ctx && result_host, "NULL argument");
-    int rc = armon_hip_dtCFL_async(ctx, r, dx, dy, u, v, c, ctx->scalars);
+    T* dev = reinterpret_cast<T*>(ctx->scalars);
+    T* host = reinterpret_cast<T*>(ctx->host_scalars);
+    int rc = dtCFL_async_impl<T>(ctx, r, dx, dy, u, v, c, dev);
     if (rc != ARMON_OK) return rc;
-    ARMON_HIP_TRY(hipMemcpyAsync(ctx->host_scalars, ctx->scalars, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ARMON_HIP_TRY(hipMemcpyAsync(host, dev, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
     ARMON_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *result_host = ctx->host_scalars[0];
+    *result_host = host[0];
     return ARMON_OK;
 }
 
-int armon_hip_conservation_vars(armon_ctx* ctx, armon_range r, double ds, const double* rho,
-                                const double* E, double out_host[2])
+template <typename T>
+int conservation_vars_impl(armon_ctx* ctx, armon_range r, T ds, const T* rho, const T* E, T out_host[2])
 {
     ARMON_REQUIRE(ctx && out_host, "NULL argument");
     ARMON_REQUIRE(range_ok(r), "invalid range");
@@ -141,17 +146,37 @@ int armon_hip_conservation_vars(armon_ctx* ctx, armon_range r, double ds, const 
     const int64_t n = (int64_t)grid.x * grid.y;
     int rc = ensure_partials(ctx, (size_t)n * 2);
     if (rc != ARMON_OK) return rc;
-    hipLaunchKernelGGL(k_conservation_partial, grid, dim3(kBlock), 0, ctx->stream, r, rho, E, ctx->partials, n);
+    T* partials = reinterpret_cast<T*>(ctx->partials);
+    T* dev = reinterpret_cast<T*>(ctx->scalars) + 4;
+    T* host = reinterpret_cast<T*>(ctx->host_scalars) + 4;
+    hipLaunchKernelGGL(k_conservation_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, rho, E, partials, n);
     rc = check_launch("conservation_partial");
     if (rc != ARMON_OK) return rc;
-    hipLaunchKernelGGL((k_fold<op_sum, 2>), dim3(1), dim3(kBlock), 0, ctx->stream, ctx->partials, n, ds, ctx->scalars + 2);
+    hipLaunchKernelGGL((k_fold<op_sum, 2, T>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, n, ds, dev);
     rc = check_launch("conservation_fold");
     if (rc != ARMON_OK) return rc;
-    ARMON_HIP_TRY(hipMemcpyAsync(ctx->host_scalars + 2, ctx->scalars + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ARMON_HIP_TRY(hipMemcpyAsync(host, dev, 2 * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
     ARMON_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    out_host[0] = ctx->host_scalars[2];
-    out_host[1] = ctx->host_scalars[3];
+    out_host[0] = host[0];
+    out_host[1] = host[1];
     return ARMON_OK;
 }
+
+}  // namespace
+
+#define ARMON_EXPORT(name, impl, PARAMS, ARGS)                                            \
+    int armon_hip_##name(PARAMS(double)) { return impl<double> ARGS; }                    \
+    int armon_hip_##name##_f32(PARAMS(float)) { return impl<float> ARGS; }
+
+extern "C" {
+
+#define P_DTA(T) armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, const T* v, const T* c, T* result_dev
+ARMON_EXPORT(dtCFL_async, dtCFL_async_impl, P_DTA, (ctx, r, dx, dy, u, v, c, result_dev))
+
+#define P_DT(T) armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, const T* v, const T* c, T* result_host
+ARMON_EXPORT(dtCFL, dtCFL_impl, P_DT, (ctx, r, dx, dy, u, v, c, result_host))
+
+#define P_CV(T) armon_ctx* ctx, armon_range r, T ds, const T* rho, const T* E, T out_host[2]
+ARMON_EXPORT(conservation_vars, conservation_vars_impl, P_CV, (ctx, r, ds, rho, E, out_host))
 
 }  // extern "C"

@@ -24,29 +24,31 @@ __device__ __forceinline__ int64_t row_base(const armon_range& r, int64_t j)
              j_ += gridDim.y, i = row_base((r), j_) + k_)
 
 // ---- a1: perfect_gas_EOS! (ref src/kernels.jl:4-13) ------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_perfect_gas_EOS(armon_range r, double gamma, const double* __restrict__ rho,
-                  const double* __restrict__ E, const double* __restrict__ u,
-                  const double* __restrict__ v, double* __restrict__ p, double* __restrict__ c,
-                  double* __restrict__ g)
+k_perfect_gas_EOS(armon_range r, T gamma, const T* __restrict__ rho,
+                  const T* __restrict__ E, const T* __restrict__ u,
+                  const T* __restrict__ v, T* __restrict__ p, T* __restrict__ c,
+                  T* __restrict__ g)
 {
     ARMON_FOR_RANGE(r, i) {
-        double pi, ci;
+        T pi, ci;
         phys::perfect_gas(gamma, rho[i], E[i], u[i], v[i], pi, ci);
         p[i] = pi;
         c[i] = ci;
-        g[i] = (1. + gamma) / 2;
+        g[i] = (T(1.) + gamma) / 2;
     }
 }
 
 // ---- a2: bizarrium_EOS! (ref src/kernels.jl:16-55) -------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_bizarrium_EOS(armon_range r, const double* __restrict__ rho, const double* __restrict__ u,
-                const double* __restrict__ v, const double* __restrict__ E, double* __restrict__ p,
-                double* __restrict__ c, double* __restrict__ g)
+k_bizarrium_EOS(armon_range r, const T* __restrict__ rho, const T* __restrict__ u,
+                const T* __restrict__ v, const T* __restrict__ E, T* __restrict__ p,
+                T* __restrict__ c, T* __restrict__ g)
 {
     ARMON_FOR_RANGE(r, i) {
-        double pi, ci, gi;
+        T pi, ci, gi;
         phys::bizarrium<true>(rho[i], E[i], u[i], v[i], pi, ci, gi);
         p[i] = pi;
         c[i] = ci;
@@ -55,13 +57,14 @@ k_bizarrium_EOS(armon_range r, const double* __restrict__ rho, const double* __r
 }
 
 // ---- a4: acoustic! (ref src/riemann_schemes.jl:33-43) ----------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_acoustic(armon_range r, int64_t s, double* __restrict__ us, double* __restrict__ ps,
-           const double* __restrict__ rho, const double* __restrict__ u,
-           const double* __restrict__ p, const double* __restrict__ c)
+k_acoustic(armon_range r, int64_t s, T* __restrict__ us, T* __restrict__ ps,
+           const T* __restrict__ rho, const T* __restrict__ u,
+           const T* __restrict__ p, const T* __restrict__ c)
 {
     ARMON_FOR_RANGE(r, i) {
-        double a, b;
+        T a, b;
         phys::godunov(rho[i], rho[i - s], c[i], c[i - s], u[i], u[i - s], p[i], p[i - s], a, b);
         us[i] = a;
         ps[i] = b;
@@ -69,18 +72,18 @@ k_acoustic(armon_range r, int64_t s, double* __restrict__ us, double* __restrict
 }
 
 // ---- a5: acoustic_GAD! (ref src/riemann_schemes.jl:55-104) -----------------------------------------
-template <int LIM>
+template <int LIM, typename T>
 __global__ void __launch_bounds__(kBlock)
-k_acoustic_GAD(armon_range r, int64_t s, double dt, double dx, double* __restrict__ us,
-               double* __restrict__ ps, const double* __restrict__ rho, const double* __restrict__ u,
-               const double* __restrict__ p, const double* __restrict__ c)
+k_acoustic_GAD(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us,
+               T* __restrict__ ps, const T* __restrict__ rho, const T* __restrict__ u,
+               const T* __restrict__ p, const T* __restrict__ c)
 {
     ARMON_FOR_RANGE(r, i) {
-        const double rho_mm = rho[i - 2 * s], c_mm = c[i - 2 * s], u_mm = u[i - 2 * s], p_mm = p[i - 2 * s];
-        const double rho_m = rho[i - s], c_m = c[i - s], u_m = u[i - s], p_m = p[i - s];
-        const double rho_i = rho[i], c_i = c[i], u_i = u[i], p_i = p[i];
-        const double rho_p = rho[i + s], c_p = c[i + s], u_p = u[i + s], p_p = p[i + s];
-        double us_m, ps_m, us_0, ps_0, us_p, ps_p, a, b;
+        const T rho_mm = rho[i - 2 * s], c_mm = c[i - 2 * s], u_mm = u[i - 2 * s], p_mm = p[i - 2 * s];
+        const T rho_m = rho[i - s], c_m = c[i - s], u_m = u[i - s], p_m = p[i - s];
+        const T rho_i = rho[i], c_i = c[i], u_i = u[i], p_i = p[i];
+        const T rho_p = rho[i + s], c_p = c[i + s], u_p = u[i + s], p_p = p[i + s];
+        T us_m, ps_m, us_0, ps_0, us_p, ps_p, a, b;
         phys::godunov(rho_m, rho_mm, c_m, c_mm, u_m, u_mm, p_m, p_mm, us_m, ps_m);
         phys::godunov(rho_i, rho_m, c_i, c_m, u_i, u_m, p_i, p_m, us_0, ps_0);
         phys::godunov(rho_p, rho_i, c_p, c_i, u_p, u_i, p_p, p_i, us_p, ps_p);
@@ -92,13 +95,14 @@ k_acoustic_GAD(armon_range r, int64_t s, double dt, double dx, double* __restric
 }
 
 // ---- a6: cell_update! (ref src/kernels.jl:58-68) ---------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_cell_update(armon_range r, int64_t s, double dx, double dt, const double* __restrict__ us,
-              const double* __restrict__ ps, double* __restrict__ rho, double* __restrict__ ua,
-              double* __restrict__ E)
+k_cell_update(armon_range r, int64_t s, T dx, T dt, const T* __restrict__ us,
+              const T* __restrict__ ps, T* __restrict__ rho, T* __restrict__ ua,
+              T* __restrict__ E)
 {
     ARMON_FOR_RANGE(r, i) {
-        double rho_i = rho[i], ua_i = ua[i], E_i = E[i];
+        T rho_i = rho[i], ua_i = ua[i], E_i = E[i];
         phys::cell_update(dx, dt, us[i], ps[i], us[i + s], ps[i + s], rho_i, ua_i, E_i);
         rho[i] = rho_i;
         ua[i] = ua_i;
@@ -107,17 +111,18 @@ k_cell_update(armon_range r, int64_t s, double dx, double dt, const double* __re
 }
 
 // ---- a7: advection_first_order! (ref src/projection_schemes.jl:62-78) ------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_advection_first_order(armon_range r, int64_t s, double dt, const double* __restrict__ us,
-                        const double* __restrict__ rho, const double* __restrict__ u,
-                        const double* __restrict__ v, const double* __restrict__ E,
-                        double* __restrict__ a_rho, double* __restrict__ a_urho,
-                        double* __restrict__ a_vrho, double* __restrict__ a_Erho)
+k_advection_first_order(armon_range r, int64_t s, T dt, const T* __restrict__ us,
+                        const T* __restrict__ rho, const T* __restrict__ u,
+                        const T* __restrict__ v, const T* __restrict__ E,
+                        T* __restrict__ a_rho, T* __restrict__ a_urho,
+                        T* __restrict__ a_vrho, T* __restrict__ a_Erho)
 {
     ARMON_FOR_RANGE(r, is) {
-        double disp = dt * us[is];
+        T disp = dt * us[is];
         int64_t d = (disp > 0) ? is - s : is;
-        double rd = rho[d];
+        T rd = rho[d];
         a_rho[is] = disp * (rd);
         a_urho[is] = disp * (rd * u[d]);
         a_vrho[is] = disp * (rd * v[d]);
@@ -126,17 +131,18 @@ k_advection_first_order(armon_range r, int64_t s, double dt, const double* __res
 }
 
 // ---- a8: advection_second_order! (ref src/projection_schemes.jl:92-124) ----------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_advection_second_order(armon_range r, int64_t s, double dx, double dt,
-                         const double* __restrict__ us, const double* __restrict__ rho,
-                         const double* __restrict__ u, const double* __restrict__ v,
-                         const double* __restrict__ E, double* __restrict__ a_rho,
-                         double* __restrict__ a_urho, double* __restrict__ a_vrho,
-                         double* __restrict__ a_Erho)
+k_advection_second_order(armon_range r, int64_t s, T dx, T dt,
+                         const T* __restrict__ us, const T* __restrict__ rho,
+                         const T* __restrict__ u, const T* __restrict__ v,
+                         const T* __restrict__ E, T* __restrict__ a_rho,
+                         T* __restrict__ a_urho, T* __restrict__ a_vrho,
+                         T* __restrict__ a_Erho)
 {
     ARMON_FOR_RANGE(r, is) {
-        double disp = dt * us[is];
-        double Dxe;
+        T disp = dt * us[is];
+        T Dxe;
         int64_t d;
         if (disp > 0) {
             Dxe = -(dx - dt * us[is - s]);
@@ -145,19 +151,19 @@ k_advection_second_order(armon_range r, int64_t s, double dx, double dt,
             Dxe = dx + dt * us[is + s];
             d = is;
         }
-        double Dxl_m = dx + dt * (us[d] - us[d - s]);
-        double Dxl   = dx + dt * (us[d + s] - us[d]);
-        double Dxl_p = dx + dt * (us[d + 2 * s] - us[d + s]);
-        double r_m = (2 * Dxl) / (Dxl + Dxl_m);
-        double r_p = (2 * Dxl) / (Dxl + Dxl_p);
+        T Dxl_m = dx + dt * (us[d] - us[d - s]);
+        T Dxl   = dx + dt * (us[d + s] - us[d]);
+        T Dxl_p = dx + dt * (us[d + 2 * s] - us[d + s]);
+        T r_m = (2 * Dxl) / (Dxl + Dxl_m);
+        T r_p = (2 * Dxl) / (Dxl + Dxl_p);
 
-        double rm = rho[d - s], r0 = rho[d], rp = rho[d + s];
-        double sl_rho  = phys::slope_minmod(rm, r0, rp, r_m, r_p);
-        double sl_urho = phys::slope_minmod(rm * u[d - s], r0 * u[d], rp * u[d + s], r_m, r_p);
-        double sl_vrho = phys::slope_minmod(rm * v[d - s], r0 * v[d], rp * v[d + s], r_m, r_p);
-        double sl_Erho = phys::slope_minmod(rm * E[d - s], r0 * E[d], rp * E[d + s], r_m, r_p);
+        T rm = rho[d - s], r0 = rho[d], rp = rho[d + s];
+        T sl_rho  = phys::slope_minmod(rm, r0, rp, r_m, r_p);
+        T sl_urho = phys::slope_minmod(rm * u[d - s], r0 * u[d], rp * u[d + s], r_m, r_p);
+        T sl_vrho = phys::slope_minmod(rm * v[d - s], r0 * v[d], rp * v[d + s], r_m, r_p);
+        T sl_Erho = phys::slope_minmod(rm * E[d - s], r0 * E[d], rp * E[d + s], r_m, r_p);
 
-        double length_factor = Dxe / (2 * Dxl);
+        T length_factor = Dxe / (2 * Dxl);
         a_rho[is]  = disp * (r0        - sl_rho  * length_factor);
         a_urho[is] = disp * (r0 * u[d] - sl_urho * length_factor);
         a_vrho[is] = disp * (r0 * v[d] - sl_vrho * length_factor);
@@ -166,15 +172,16 @@ k_advection_second_order(armon_range r, int64_t s, double dx, double dt,
 }
 
 // ---- a9: euler_projection! (ref src/projection_schemes.jl:23-41) -----------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_euler_projection(armon_range r, int64_t s, double dx, double dt, const double* __restrict__ us,
-                   double* __restrict__ rho, double* __restrict__ u, double* __restrict__ v,
-                   double* __restrict__ E, const double* __restrict__ a_rho,
-                   const double* __restrict__ a_urho, const double* __restrict__ a_vrho,
-                   const double* __restrict__ a_Erho)
+k_euler_projection(armon_range r, int64_t s, T dx, T dt, const T* __restrict__ us,
+                   T* __restrict__ rho, T* __restrict__ u, T* __restrict__ v,
+                   T* __restrict__ E, const T* __restrict__ a_rho,
+                   const T* __restrict__ a_urho, const T* __restrict__ a_vrho,
+                   const T* __restrict__ a_Erho)
 {
     ARMON_FOR_RANGE(r, i) {
-        double rho_i = rho[i], u_i = u[i], v_i = v[i], E_i = E[i];
+        T rho_i = rho[i], u_i = u[i], v_i = v[i], E_i = E[i];
         phys::euler_projection(dx, dt, us[i], us[i + s], a_rho[i], a_rho[i + s], a_urho[i],
                                a_urho[i + s], a_vrho[i], a_vrho[i + s], a_Erho[i], a_Erho[i + s],
                                rho_i, u_i, v_i, E_i);
@@ -187,11 +194,12 @@ k_euler_projection(armon_range r, int64_t s, double dx, double dt, const double*
 
 // ---- a10: boundary_conditions! (ref src/halo_exchange.jl:2-29) -------------------------------------
 // One thread per border cell (linear over the strip), looping over the ghost layers.
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_boundary_conditions(armon_range r, int64_t incr, int nghost, double u_factor, double v_factor,
-                      double* __restrict__ rho, double* __restrict__ u, double* __restrict__ v,
-                      double* __restrict__ p, double* __restrict__ c, double* __restrict__ g,
-                      double* __restrict__ E)
+k_boundary_conditions(armon_range r, int64_t incr, int nghost, T u_factor, T v_factor,
+                      T* __restrict__ rho, T* __restrict__ u, T* __restrict__ v,
+                      T* __restrict__ p, T* __restrict__ c, T* __restrict__ g,
+                      T* __restrict__ E)
 {
     const int64_t n = r.col_len * r.row_len;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
@@ -215,11 +223,11 @@ k_boundary_conditions(armon_range r, int64_t incr, int nghost, double u_factor, 
 
 // ---- a13: pack_to_array! / unpack_from_array! (ref src/halo_exchange.jl:187-216) -------------------
 constexpr int kMaxPackVars = 8;
-struct pack_vars { double* v[kMaxPackVars]; };   // passed by value: no device-side pointer table
+template <typename T> struct pack_vars { T* v[kMaxPackVars]; };   // passed by value: no device-side pointer table
 
-template <bool PACK>
+template <bool PACK, typename T>
 __global__ void __launch_bounds__(kBlock)
-k_pack(armon_range r, int nghost, int64_t face, double* __restrict__ array, int nvars, pack_vars vars)
+k_pack(armon_range r, int nghost, int64_t face, T* __restrict__ array, int nvars, pack_vars<T> vars)
 {
     const int64_t n = r.col_len * r.row_len;
     for (int64_t itr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; itr < n;
@@ -236,38 +244,44 @@ k_pack(armon_range r, int nghost, int64_t face, double* __restrict__ array, int 
 }
 
 // ---- a16: init_test (ref src/kernels.jl:71-145, src/tests.jl:59-121) -------------------------------
-struct two_state { double hi_rho, lo_rho, hi_E, lo_E, hi_u, lo_u, hi_v, lo_v; };
+template <typename T> struct block_ptrs {
+    T *x, *y, *rho, *u, *v, *E, *p, *c, *g, *us, *ps, *work_1, *work_2, *work_3, *work_4, *mask;
+};
 
-__device__ __forceinline__ bool region_high(int test, double x, double y, double sedov_r)
+template <typename T> struct two_state { T hi_rho, lo_rho, hi_E, lo_E, hi_u, lo_u, hi_v, lo_v; };
+
+template <typename T>
+__device__ __forceinline__ bool region_high(int test, T x, T y, T sedov_r)
 {
     switch (test) {
-    case ARMON_TEST_SOD:       return x <= 0.5;
-    case ARMON_TEST_SOD_Y:     return y <= 0.5;
-    case ARMON_TEST_SOD_CIRC:  return (x - 0.5) * (x - 0.5) + (y - 0.5) * (y - 0.5) <= 0.09;
-    case ARMON_TEST_BIZARRIUM: return x <= 0.5;
+    case ARMON_TEST_SOD:       return x <= T(0.5);
+    case ARMON_TEST_SOD_Y:     return y <= T(0.5);
+    case ARMON_TEST_SOD_CIRC:  return (x - T(0.5)) * (x - T(0.5)) + (y - T(0.5)) * (y - T(0.5)) <= T(0.09);
+    case ARMON_TEST_BIZARRIUM: return x <= T(0.5);
     case ARMON_TEST_SEDOV:     return x * x + y * y <= sedov_r * sedov_r;
     default:                   return false;
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_init_test(armon_range r, int test, int64_t row_length, int64_t nx, int64_t ny, int nghost,
-            int64_t gpos_x, int64_t gpos_y, int64_t gN_x, double ox, double oy, double dXx, double dXy,
-            double sedov_r, two_state tp, armon_block_data d)
+            int64_t gpos_x, int64_t gpos_y, int64_t gN_x, T ox, T oy, T dXx, T dXy,
+            T sedov_r, two_state<T> tp, block_ptrs<T> d)
 {
     ARMON_FOR_RANGE(r, i) {
         int64_t Iy = i / row_length;
         int64_t Ix = i - Iy * row_length - nghost + 1;
         Iy = Iy - nghost + 1;
         int64_t gx = Ix + gpos_x - 1, gy = Iy + gpos_y - 1;
-        double x = (double)gx * dXx + ox;
-        double y = (double)gy * dXy + oy;
+        T x = (T)gx * dXx + ox;
+        T y = (T)gy * dXy + oy;
         d.x[i] = x;
         d.y[i] = y;
         bool ghost = !(Ix >= 1 && Ix <= nx && Iy >= 1 && Iy <= ny);
-        d.mask[i] = ghost ? 0. : 1.;
+        d.mask[i] = ghost ? T(0.) : T(1.);
         if (test == ARMON_TEST_DEBUG_INDEXES) {
-            double gi = (double)(gx + gy * gN_x + 1);
+            T gi = (T)(gx + gy * gN_x + 1);
             d.rho[i] = gi; d.E[i] = gi; d.u[i] = gi; d.v[i] = gi; d.p[i] = gi; d.c[i] = gi; d.g[i] = gi;
         } else {
             bool hi = region_high(test, x + dXx / 2, y + dXy / 2, sedov_r);
@@ -299,46 +313,48 @@ inline void linear_grid(const armon_ctx* ctx, int64_t n, dim3& grid, dim3& block
                   (long long)(r).row_start, (long long)(r).row_len);                   \
     if (range_empty(r)) return ARMON_OK
 
-extern "C" {
+// ---- implementations, generic in the working precision ---------------------------------------------------
+namespace {
 
-int armon_hip_perfect_gas_EOS(armon_ctx* ctx, armon_range r, double gamma, const double* rho,
-                              const double* E, const double* u, const double* v, double* p,
-                              double* c, double* g)
+template <typename T>
+int perfect_gas_EOS_impl(armon_ctx* ctx, armon_range r, T gamma, const T* rho, const T* E, const T* u, const T* v,
+                         T* p, T* c, T* g)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(rho && E && u && v && p && c && g, "NULL array");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_perfect_gas_EOS, grid, block, 0, ctx->stream, r, gamma, rho, E, u, v, p, c, g);
+    hipLaunchKernelGGL(k_perfect_gas_EOS<T>, grid, block, 0, ctx->stream, r, gamma, rho, E, u, v, p, c, g);
     return check_launch("perfect_gas_EOS");
 }
 
-int armon_hip_bizarrium_EOS(armon_ctx* ctx, armon_range r, const double* rho, const double* u,
-                            const double* v, const double* E, double* p, double* c, double* g)
+template <typename T>
+int bizarrium_EOS_impl(armon_ctx* ctx, armon_range r, const T* rho, const T* u, const T* v, const T* E,
+                       T* p, T* c, T* g)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(rho && E && u && v && p && c && g, "NULL array");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_bizarrium_EOS, grid, block, 0, ctx->stream, r, rho, u, v, E, p, c, g);
+    hipLaunchKernelGGL(k_bizarrium_EOS<T>, grid, block, 0, ctx->stream, r, rho, u, v, E, p, c, g);
     return check_launch("bizarrium_EOS");
 }
 
-int armon_hip_acoustic(armon_ctx* ctx, armon_range r, int64_t s, double* us, double* ps,
-                       const double* rho, const double* ua, const double* p, const double* c)
+template <typename T>
+int acoustic_impl(armon_ctx* ctx, armon_range r, int64_t s, T* us, T* ps, const T* rho, const T* ua, const T* p, const T* c)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(us && ps && rho && ua && p && c, "NULL array");
     ARMON_REQUIRE(s > 0, "stride must be positive");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_acoustic, grid, block, 0, ctx->stream, r, s, us, ps, rho, ua, p, c);
+    hipLaunchKernelGGL(k_acoustic<T>, grid, block, 0, ctx->stream, r, s, us, ps, rho, ua, p, c);
     return check_launch("acoustic");
 }
 
-int armon_hip_acoustic_GAD(armon_ctx* ctx, armon_range r, int64_t s, double dt, double dx,
-                           double* us, double* ps, const double* rho, const double* ua,
-                           const double* p, const double* c, int limiter)
+template <typename T>
+int acoustic_GAD_impl(armon_ctx* ctx, armon_range r, int64_t s, T dt, T dx, T* us, T* ps, const T* rho, const T* ua,
+                      const T* p, const T* c, int limiter)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(us && ps && rho && ua && p && c, "NULL array");
@@ -347,13 +363,13 @@ int armon_hip_acoustic_GAD(armon_ctx* ctx, armon_range r, int64_t s, double dt, 
     range_grid(r, 1, grid, block);
     switch (limiter) {
     case ARMON_LIMITER_NONE:
-        hipLaunchKernelGGL(k_acoustic_GAD<ARMON_LIMITER_NONE>, grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
+        hipLaunchKernelGGL((k_acoustic_GAD<ARMON_LIMITER_NONE, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
         break;
     case ARMON_LIMITER_MINMOD:
-        hipLaunchKernelGGL(k_acoustic_GAD<ARMON_LIMITER_MINMOD>, grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
+        hipLaunchKernelGGL((k_acoustic_GAD<ARMON_LIMITER_MINMOD, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
         break;
     case ARMON_LIMITER_SUPERBEE:
-        hipLaunchKernelGGL(k_acoustic_GAD<ARMON_LIMITER_SUPERBEE>, grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
+        hipLaunchKernelGGL((k_acoustic_GAD<ARMON_LIMITER_SUPERBEE, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
         break;
     default:
         ARMON_REQUIRE(false, "unknown limiter tag %d", limiter);
@@ -361,140 +377,190 @@ int armon_hip_acoustic_GAD(armon_ctx* ctx, armon_range r, int64_t s, double dt, 
     return check_launch("acoustic_GAD");
 }
 
-int armon_hip_cell_update(armon_ctx* ctx, armon_range r, int64_t s, double dx, double dt,
-                          const double* us, const double* ps, double* rho, double* ua, double* E)
+template <typename T>
+int cell_update_impl(armon_ctx* ctx, armon_range r, int64_t s, T dx, T dt, const T* us, const T* ps, T* rho, T* ua, T* E)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(us && ps && rho && ua && E, "NULL array");
     ARMON_REQUIRE(s > 0, "stride must be positive");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_cell_update, grid, block, 0, ctx->stream, r, s, dx, dt, us, ps, rho, ua, E);
+    hipLaunchKernelGGL(k_cell_update<T>, grid, block, 0, ctx->stream, r, s, dx, dt, us, ps, rho, ua, E);
     return check_launch("cell_update");
 }
 
-int armon_hip_advection_first_order(armon_ctx* ctx, armon_range r, int64_t s, double dt,
-                                    const double* us, const double* rho, const double* u,
-                                    const double* v, const double* E, double* a_rho,
-                                    double* a_urho, double* a_vrho, double* a_Erho)
+template <typename T>
+int advection_first_order_impl(armon_ctx* ctx, armon_range r, int64_t s, T dt, const T* us, const T* rho, const T* u,
+                               const T* v, const T* E, T* a_rho, T* a_urho, T* a_vrho, T* a_Erho)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(us && rho && u && v && E && a_rho && a_urho && a_vrho && a_Erho, "NULL array");
     ARMON_REQUIRE(s > 0, "stride must be positive");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_advection_first_order, grid, block, 0, ctx->stream, r, s, dt, us, rho, u, v, E,
+    hipLaunchKernelGGL(k_advection_first_order<T>, grid, block, 0, ctx->stream, r, s, dt, us, rho, u, v, E,
                        a_rho, a_urho, a_vrho, a_Erho);
     return check_launch("advection_first_order");
 }
 
-int armon_hip_advection_second_order(armon_ctx* ctx, armon_range r, int64_t s, double dx, double dt,
-                                     const double* us, const double* rho, const double* u,
-                                     const double* v, const double* E, double* a_rho,
-                                     double* a_urho, double* a_vrho, double* a_Erho)
+template <typename T>
+int advection_second_order_impl(armon_ctx* ctx, armon_range r, int64_t s, T dx, T dt, const T* us, const T* rho,
+                                const T* u, const T* v, const T* E, T* a_rho, T* a_urho, T* a_vrho, T* a_Erho)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(us && rho && u && v && E && a_rho && a_urho && a_vrho && a_Erho, "NULL array");
     ARMON_REQUIRE(s > 0, "stride must be positive");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_advection_second_order, grid, block, 0, ctx->stream, r, s, dx, dt, us, rho, u,
+    hipLaunchKernelGGL(k_advection_second_order<T>, grid, block, 0, ctx->stream, r, s, dx, dt, us, rho, u,
                        v, E, a_rho, a_urho, a_vrho, a_Erho);
     return check_launch("advection_second_order");
 }
 
-int armon_hip_euler_projection(armon_ctx* ctx, armon_range r, int64_t s, double dx, double dt,
-                               const double* us, double* rho, double* u, double* v, double* E,
-                               const double* a_rho, const double* a_urho, const double* a_vrho,
-                               const double* a_Erho)
+template <typename T>
+int euler_projection_impl(armon_ctx* ctx, armon_range r, int64_t s, T dx, T dt, const T* us, T* rho, T* u, T* v, T* E,
+                          const T* a_rho, const T* a_urho, const T* a_vrho, const T* a_Erho)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(us && rho && u && v && E && a_rho && a_urho && a_vrho && a_Erho, "NULL array");
     ARMON_REQUIRE(s > 0, "stride must be positive");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_euler_projection, grid, block, 0, ctx->stream, r, s, dx, dt, us, rho, u, v, E,
+    hipLaunchKernelGGL(k_euler_projection<T>, grid, block, 0, ctx->stream, r, s, dx, dt, us, rho, u, v, E,
                        a_rho, a_urho, a_vrho, a_Erho);
     return check_launch("euler_projection");
 }
 
-int armon_hip_boundary_conditions(armon_ctx* ctx, armon_range r, int64_t incr, int nghost,
-                                  double u_factor, double v_factor, double* rho, double* u,
-                                  double* v, double* p, double* c, double* g, double* E)
+template <typename T>
+int boundary_conditions_impl(armon_ctx* ctx, armon_range r, int64_t incr, int nghost, T u_factor, T v_factor,
+                             T* rho, T* u, T* v, T* p, T* c, T* g, T* E)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(rho && u && v && p && c && g && E, "NULL array");
     ARMON_REQUIRE(incr != 0 && nghost > 0, "invalid incr/nghost");
     dim3 grid, block;
     linear_grid(ctx, r.col_len * r.row_len, grid, block);
-    hipLaunchKernelGGL(k_boundary_conditions, grid, block, 0, ctx->stream, r, incr, nghost, u_factor,
+    hipLaunchKernelGGL(k_boundary_conditions<T>, grid, block, 0, ctx->stream, r, incr, nghost, u_factor,
                        v_factor, rho, u, v, p, c, g, E);
     return check_launch("boundary_conditions");
 }
 
-static int pack_common(armon_ctx* ctx, armon_range r, int nghost, int64_t face, double* array,
-                       int nvars, const double* const* vars, bool pack)
+template <typename T>
+int pack_impl(armon_ctx* ctx, armon_range r, int nghost, int64_t face, T* array, int nvars, const T* const* vars, bool pack)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(array && vars, "NULL array");
     ARMON_REQUIRE(nvars > 0 && nvars <= kMaxPackVars, "nvars must be in [1,%d]", kMaxPackVars);
     ARMON_REQUIRE(nghost > 0 && face > 0, "invalid nghost/face");
     ARMON_REQUIRE(r.col_len * r.row_len <= face * nghost, "range larger than face*nghost");
-    pack_vars table = {};
+    pack_vars<T> table = {};
     for (int v = 0; v < nvars; v++) {
         ARMON_REQUIRE(vars[v] != nullptr, "NULL array in vars[%d]", v);
-        table.v[v] = const_cast<double*>(vars[v]);
+        table.v[v] = const_cast<T*>(vars[v]);
     }
     dim3 grid, block;
     linear_grid(ctx, r.col_len * r.row_len, grid, block);
     if (pack)
-        hipLaunchKernelGGL(k_pack<true>, grid, block, 0, ctx->stream, r, nghost, face, array, nvars, table);
+        hipLaunchKernelGGL((k_pack<true, T>), grid, block, 0, ctx->stream, r, nghost, face, array, nvars, table);
     else
-        hipLaunchKernelGGL(k_pack<false>, grid, block, 0, ctx->stream, r, nghost, face, array, nvars, table);
+        hipLaunchKernelGGL((k_pack<false, T>), grid, block, 0, ctx->stream, r, nghost, face, array, nvars, table);
     return check_launch(pack ? "pack_to_array" : "unpack_from_array");
 }
 
-int armon_hip_pack_to_array(armon_ctx* ctx, armon_range r, int nghost, int64_t face, double* array,
-                            int nvars, const double* const* vars)
+template <typename T>
+int unpack_impl(armon_ctx* ctx, armon_range r, int nghost, int64_t face, const T* array, int nvars, T* const* vars)
 {
-    return pack_common(ctx, r, nghost, face, array, nvars, vars, true);
+    return pack_impl<T>(ctx, r, nghost, face, const_cast<T*>(array), nvars, const_cast<const T* const*>(vars), false);
 }
 
-int armon_hip_unpack_from_array(armon_ctx* ctx, armon_range r, int nghost, int64_t face,
-                                const double* array, int nvars, double* const* vars)
-{
-    return pack_common(ctx, r, nghost, face, const_cast<double*>(array), nvars,
-                       const_cast<const double* const*>(vars), false);
-}
-
-int armon_hip_init_test(armon_ctx* ctx, armon_range r, int test, int64_t row_length,
-                        int64_t col_length, int nghost, const int64_t global_pos[2],
-                        const int64_t global_N[2], const double origin[2], const double dX[2],
-                        double sedov_r, const armon_block_data* d)
+template <typename T, typename BD>
+int init_test_impl(armon_ctx* ctx, armon_range r, int test, int64_t row_length, int64_t col_length, int nghost,
+                   const int64_t global_pos[2], const int64_t global_N[2], const T origin[2], const T dX[2],
+                   T sedov_r, const BD* d)
 {
     ARMON_CHECK_CTX_RANGE(ctx, r);
     ARMON_REQUIRE(global_pos && global_N && origin && dX && d, "NULL argument");
     ARMON_REQUIRE(test >= ARMON_TEST_SOD && test <= ARMON_TEST_DEBUG_INDEXES, "unknown test tag %d", test);
-    const double* const* arrs = reinterpret_cast<const double* const*>(d);
+    static_assert(sizeof(BD) == 16 * sizeof(T*), "block data = 16 pointers");
+    T* const* arrs = reinterpret_cast<T* const*>(d);
     for (int k = 0; k < 16; k++) ARMON_REQUIRE(arrs[k] != nullptr, "NULL array in block data (field %d)", k);
+    block_ptrs<T> bp;
+    memcpy(&bp, d, sizeof(bp));
     // ref src/tests.jl:84-121
-    two_state tp;
+    two_state<T> tp;
     switch (test) {
     case ARMON_TEST_BIZARRIUM:
-        tp = { 1.42857142857e+4, 10000., 4.48657821135e+6, 0.5 * (250. * 250.), 0., 250., 0., 0. };
+        tp = { T(1.42857142857e+4), T(10000.), T(4.48657821135e+6), T(0.5 * (250. * 250.)), T(0.), T(250.), T(0.), T(0.) };
         break;
     case ARMON_TEST_SEDOV:
-        tp = { 1., 1., pow(1. / 1.033, 5) / (M_PI * (sedov_r * sedov_r)), 2.5e-14, 0., 0., 0., 0. };
+        // ref src/tests.jl:112: T((1/1.033)^5 / (π * p.r^2)) — π·r² in T, the quotient in Float64
+        tp = { T(1.), T(1.), T(pow(1. / 1.033, 5) / (double)(T(M_PI) * (sedov_r * sedov_r))), T(2.5e-14), T(0.), T(0.), T(0.), T(0.) };
         break;
     default:
-        tp = { 1., 0.125, 2.5, 2.0, 0., 0., 0., 0. };
+        tp = { T(1.), T(0.125), T(2.5), T(2.0), T(0.), T(0.), T(0.), T(0.) };
     }
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_init_test, grid, block, 0, ctx->stream, r, test, row_length,
+    hipLaunchKernelGGL(k_init_test<T>, grid, block, 0, ctx->stream, r, test, row_length,
                        row_length - 2 * nghost, col_length - 2 * nghost, nghost, global_pos[0],
-                       global_pos[1], global_N[0], origin[0], origin[1], dX[0], dX[1], sedov_r, tp, *d);
+                       global_pos[1], global_N[0], origin[0], origin[1], dX[0], dX[1], sedov_r, tp, bp);
     return check_launch("init_test");
+}
+
+}  // namespace
+
+// ---- C ABI: every entry point exists for fp64 (reference names) and fp32 (`_f32` suffix) -------------------------
+#define ARMON_EXPORT(name, impl, PARAMS, ARGS)                                            \
+    int armon_hip_##name(PARAMS(double)) { return impl<double> ARGS; }                    \
+    int armon_hip_##name##_f32(PARAMS(float)) { return impl<float> ARGS; }
+
+extern "C" {
+
+#define P_PG(T) armon_ctx* ctx, armon_range r, T gamma, const T* rho, const T* E, const T* u, const T* v, T* p, T* c, T* g
+ARMON_EXPORT(perfect_gas_EOS, perfect_gas_EOS_impl, P_PG, (ctx, r, gamma, rho, E, u, v, p, c, g))
+
+#define P_BZ(T) armon_ctx* ctx, armon_range r, const T* rho, const T* u, const T* v, const T* E, T* p, T* c, T* g
+ARMON_EXPORT(bizarrium_EOS, bizarrium_EOS_impl, P_BZ, (ctx, r, rho, u, v, E, p, c, g))
+
+#define P_AC(T) armon_ctx* ctx, armon_range r, int64_t s, T* us, T* ps, const T* rho, const T* ua, const T* p, const T* c
+ARMON_EXPORT(acoustic, acoustic_impl, P_AC, (ctx, r, s, us, ps, rho, ua, p, c))
+
+#define P_GAD(T) armon_ctx* ctx, armon_range r, int64_t s, T dt, T dx, T* us, T* ps, const T* rho, const T* ua, const T* p, const T* c, int limiter
+ARMON_EXPORT(acoustic_GAD, acoustic_GAD_impl, P_GAD, (ctx, r, s, dt, dx, us, ps, rho, ua, p, c, limiter))
+
+#define P_CU(T) armon_ctx* ctx, armon_range r, int64_t s, T dx, T dt, const T* us, const T* ps, T* rho, T* ua, T* E
+ARMON_EXPORT(cell_update, cell_update_impl, P_CU, (ctx, r, s, dx, dt, us, ps, rho, ua, E))
+
+#define P_A1(T) armon_ctx* ctx, armon_range r, int64_t s, T dt, const T* us, const T* rho, const T* u, const T* v, const T* E, T* a_rho, T* a_urho, T* a_vrho, T* a_Erho
+ARMON_EXPORT(advection_first_order, advection_first_order_impl, P_A1, (ctx, r, s, dt, us, rho, u, v, E, a_rho, a_urho, a_vrho, a_Erho))
+
+#define P_A2(T) armon_ctx* ctx, armon_range r, int64_t s, T dx, T dt, const T* us, const T* rho, const T* u, const T* v, const T* E, T* a_rho, T* a_urho, T* a_vrho, T* a_Erho
+ARMON_EXPORT(advection_second_order, advection_second_order_impl, P_A2, (ctx, r, s, dx, dt, us, rho, u, v, E, a_rho, a_urho, a_vrho, a_Erho))
+
+#define P_EP(T) armon_ctx* ctx, armon_range r, int64_t s, T dx, T dt, const T* us, T* rho, T* u, T* v, T* E, const T* a_rho, const T* a_urho, const T* a_vrho, const T* a_Erho
+ARMON_EXPORT(euler_projection, euler_projection_impl, P_EP, (ctx, r, s, dx, dt, us, rho, u, v, E, a_rho, a_urho, a_vrho, a_Erho))
+
+#define P_BC(T) armon_ctx* ctx, armon_range r, int64_t incr, int nghost, T u_factor, T v_factor, T* rho, T* u, T* v, T* p, T* c, T* g, T* E
+ARMON_EXPORT(boundary_conditions, boundary_conditions_impl, P_BC, (ctx, r, incr, nghost, u_factor, v_factor, rho, u, v, p, c, g, E))
+
+#define P_PK(T) armon_ctx* ctx, armon_range r, int nghost, int64_t face, T* array, int nvars, const T* const* vars
+ARMON_EXPORT(pack_to_array, pack_impl, P_PK, (ctx, r, nghost, face, array, nvars, vars, true))
+
+#define P_UP(T) armon_ctx* ctx, armon_range r, int nghost, int64_t face, const T* array, int nvars, T* const* vars
+ARMON_EXPORT(unpack_from_array, unpack_impl, P_UP, (ctx, r, nghost, face, array, nvars, vars))
+
+int armon_hip_init_test(armon_ctx* ctx, armon_range r, int test, int64_t row_length, int64_t col_length, int nghost,
+                        const int64_t global_pos[2], const int64_t global_N[2], const double origin[2],
+                        const double dX[2], double sedov_r, const armon_block_data* d)
+{
+    return init_test_impl<double>(ctx, r, test, row_length, col_length, nghost, global_pos, global_N, origin, dX, sedov_r, d);
+}
+
+int armon_hip_init_test_f32(armon_ctx* ctx, armon_range r, int test, int64_t row_length, int64_t col_length, int nghost,
+                            const int64_t global_pos[2], const int64_t global_N[2], const float origin[2],
+                            const float dX[2], float sedov_r, const armon_block_data_f32* d)
+{
+    return init_test_impl<float>(ctx, r, test, row_length, col_length, nghost, global_pos, global_N, origin, dX, sedov_r, d);
 }
 
 }  // extern "C"

@@ -31,7 +31,7 @@
 namespace armon {
 namespace fused {
 
-struct Out4 { double rho, ua, ut, E; };
+template <typename T> struct Out4 { T rho, ua, ut, E; };
 
 template <int SCHEME_, int LIM_, int PROJ_, int EOS_>
 struct PipeTraits {
@@ -44,35 +44,36 @@ struct PipeTraits {
 // ======================================================================================================
 // EXACT pipeline
 // ======================================================================================================
-template <int SCHEME, int LIM, int PROJ, int EOS>
+template <int SCHEME, int LIM, int PROJ, int EOS, typename T = double>
 struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
+    using real = T;
     using TR = PipeTraits<SCHEME, LIM, PROJ, EOS>;
     static constexpr int S = TR::S, W = TR::W, LAG = TR::LAG;
     static constexpr bool kExact = true;
 
-    struct Cell { double rho, ua, ut, E, p, rc; };                 // pre-sweep state + EOS
-    struct Upd { double rho, ua, ut, E, q_ua, q_ut, q_E, dxl; };   // Lagrangian (post cell_update) state
+    struct Cell { T rho, ua, ut, E, p, rc; };                 // pre-sweep state + EOS
+    struct Upd { T rho, ua, ut, E, q_ua, q_ut, q_E, dxl; };   // Lagrangian (post cell_update) state
 
-    double dt, dx, gamma;
+    T dt, dx, gamma;
     Cell c[8];                  // ring of 8: cells j+4 .. j (prefetched), j-1, j-2
-    double gus[4], gps[4];      // ring: first-order solutions at interfaces j, j-1, j-2
-    double fus[4], fps[4];      // ring: final fluxes at interfaces nf .. nf-3
+    T gus[4], gps[4];      // ring: first-order solutions at interfaces j, j-1, j-2
+    T fus[4], fps[4];      // ring: final fluxes at interfaces nf .. nf-3
     Upd l[4];                   // ring: updated cells cu, cu-1, cu-2   (cu = nf - 1)
-    double s[2][4];             // minmod slopes of cells cu-1 / cu-2
-    double a[2][4];             // advection fluxes at interfaces na / na-1
-    double csr[4];              // ring: sound speed of cells j .. j-3 (dt/CFL tracking only)
+    T s[2][4];             // minmod slopes of cells cu-1 / cu-2
+    T a[2][4];             // advection fluxes at interfaces na / na-1
+    T csr[4];              // ring: sound speed of cells j .. j-3 (dt/CFL tracking only)
 
-    __device__ __forceinline__ Pipe(double dt_, double dx_, double gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
+    __device__ __forceinline__ Pipe(T dt_, T dx_, T gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
     {
         // Neutral, finite start values: the first 2*LAG outputs are discarded by the caller.
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = Cell{1., 0., 0., 1., 1., 1.};
+        for (int k = 0; k < 8; k++) c[k] = Cell{T(1.), T(0.), T(0.), T(1.), T(1.), T(1.)};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            gus[k] = 0.; gps[k] = 1.; fus[k] = 0.; fps[k] = 1.; csr[k] = 1.;
-            l[k] = Upd{1., 0., 0., 1., 0., 0., 1., dx_};
-            s[0][k] = s[1][k] = 0.;
-            a[0][k] = a[1][k] = 0.;
+            gus[k] = T(0.); gps[k] = T(1.); fus[k] = T(0.); fps[k] = T(1.); csr[k] = T(1.);
+            l[k] = Upd{T(1.), T(0.), T(0.), T(1.), T(0.), T(0.), T(1.), dx_};
+            s[0][k] = s[1][k] = T(0.);
+            a[0][k] = a[1][k] = T(0.);
         }
     }
 
@@ -80,7 +81,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     // j - LAG. PH8 = step index mod 8. p_j, c_j: EOS of cell j, for optional materialisation.
     // c_lag: the (pre-sweep) sound speed of the emitted cell j - LAG, for the fused dt/CFL reduction.
     template <bool Y_AXIS, int PH8>
-    __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j, double& c_lag)
+    __device__ __forceinline__ Out4<T> push(T rho, T ua, T ut, T E, T& p_j, T& c_j, T& c_lag)
     {
         Cell& n = c[PH8 & 7];
         n.rho = rho; n.ua = ua; n.ut = ut; n.E = E;
@@ -89,7 +90,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 
     // Same, with (ρ, ua, ut, E) of cell j already stored in c[PH8 & 7] by the caller's prefetch.
     template <bool Y_AXIS, int PH8>
-    __device__ __forceinline__ Out4 advance(double& p_j, double& c_j, double& c_lag)
+    __device__ __forceinline__ Out4<T> advance(T& p_j, T& c_j, T& c_lag)
     {
         constexpr int PH = PH8 & 3;
         constexpr int R0 = PH & 3, R1 = (PH - 1) & 3, R2 = (PH - 2) & 3, R3 = (PH - 3) & 3;
@@ -100,11 +101,11 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         const Cell& c2 = c[(PH8 - 2) & 7];
 
         // ---- EOS (ref src/kernels.jl:4-55): e = E - 0.5*(u² + v²) with u, v in the reference's order
-        double p, cs;
+        T p, cs;
         {
-            const double u = Y_AXIS ? c0.ut : c0.ua, v = Y_AXIS ? c0.ua : c0.ut;
+            const T u = Y_AXIS ? c0.ut : c0.ua, v = Y_AXIS ? c0.ua : c0.ut;
             if (EOS == ARMON_EOS_BIZARRIUM) {
-                double g_unused;
+                T g_unused;
                 phys::bizarrium<false>(c0.rho, c0.E, u, v, p, cs, g_unused);
             } else {
                 phys::perfect_gas(gamma, c0.rho, c0.E, u, v, p, cs);
@@ -118,7 +119,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 
         // ---- first-order acoustic solve at interface j (ref src/riemann_schemes.jl:21-30)
         {
-            const double rc_l = c1.rc, rc_r = c0.rc;
+            const T rc_l = c1.rc, rc_r = c0.rc;
             gus[R0] = (rc_l * c1.ua + rc_r * c0.ua + (c1.p - c0.p)) / (rc_l + rc_r);
             gps[R0] = (rc_r * c1.p + rc_l * c0.p + rc_l * rc_r * (c1.ua - c0.ua)) / (rc_l + rc_r);
         }
@@ -126,29 +127,29 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         // ---- final flux at interface nf = j - S
         if (S == 1) {
             // acoustic_GAD! at interface i = j-1: cells i-s = c2, i = c1 (ref src/riemann_schemes.jl:84-104)
-            const double gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
-            const double r_um = phys::limiter<LIM>((gus0 - c1.ua) / (gus1 - c2.ua + 1e-6));
-            const double r_pm = phys::limiter<LIM>((gps0 - c1.p) / (gps1 - c2.p + 1e-6));
-            const double r_up = phys::limiter<LIM>((c2.ua - gus2) / (c1.ua - gus1 + 1e-6));
-            const double r_pp = phys::limiter<LIM>((c2.p - gps2) / (c1.p - gps1 + 1e-6));
-            const double dm_l = c2.rho * dx;
-            const double dm_r = c1.rho * dx;
-            const double Dm = (dm_l + dm_r) / 2;
-            const double theta = 0.5 * (1 - (c2.rc + c1.rc) / 2 * (dt / Dm));
+            const T gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
+            const T r_um = phys::limiter<LIM>((gus0 - c1.ua) / (gus1 - c2.ua + T(1e-6)));
+            const T r_pm = phys::limiter<LIM>((gps0 - c1.p) / (gps1 - c2.p + T(1e-6)));
+            const T r_up = phys::limiter<LIM>((c2.ua - gus2) / (c1.ua - gus1 + T(1e-6)));
+            const T r_pp = phys::limiter<LIM>((c2.p - gps2) / (c1.p - gps1 + T(1e-6)));
+            const T dm_l = c2.rho * dx;
+            const T dm_r = c1.rho * dx;
+            const T Dm = (dm_l + dm_r) / 2;
+            const T theta = T(0.5) * (1 - (c2.rc + c1.rc) / 2 * (dt / Dm));
             fus[R0] = gus1 + theta * (r_up * (c1.ua - gus1) - r_um * (gus1 - c2.ua));
             fps[R0] = gps1 + theta * (r_pp * (c1.p - gps1) - r_pm * (gps1 - c2.p));
         } else {
             fus[R0] = gus[R0];
             fps[R0] = gps[R0];
         }
-        const double fus0 = fus[R0], fps0 = fps[R0], fus1 = fus[R1], fps1 = fps[R1], fus2 = fus[R2], fus3 = fus[R3];
+        const T fus0 = fus[R0], fps0 = fps[R0], fus1 = fus[R1], fps1 = fps[R1], fus2 = fus[R2], fus3 = fus[R3];
 
         // ---- Lagrangian update of cell cu = nf - 1 (ref src/kernels.jl:58-68)
         {
             const Cell& cc = (S == 1) ? c2 : c1;
             Upd& n = l[R0];
-            const double dm = cc.rho * dx;
-            const double dxl = dx + dt * (fus0 - fus1);
+            const T dm = cc.rho * dx;
+            const T dxl = dx + dt * (fus0 - fus1);
             n.dxl = dxl;
             n.rho = dm / dxl;
             n.ua = cc.ua + dt / dm * (fps1 - fps0);
@@ -166,20 +167,20 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         if (W == 1) {
             // slopes of cell cu-1 (ref src/projection_schemes.jl:105-116 evaluated per donor cell);
             // s[P1] still holds the slopes of cell cu-2 from the previous step.
-            const double r_m = (2 * l1.dxl) / (l1.dxl + l2.dxl);
-            const double r_p = (2 * l1.dxl) / (l1.dxl + l0.dxl);
+            const T r_m = (2 * l1.dxl) / (l1.dxl + l2.dxl);
+            const T r_p = (2 * l1.dxl) / (l1.dxl + l0.dxl);
             // reference order of the conserved quantities: ρ, ρu, ρv, ρE
             s[P0][0] = phys::slope_minmod(l2.rho, l1.rho, l0.rho, r_m, r_p);
             s[P0][Y_AXIS ? 2 : 1] = phys::slope_minmod(l2.q_ua, l1.q_ua, l0.q_ua, r_m, r_p);
             s[P0][Y_AXIS ? 1 : 2] = phys::slope_minmod(l2.q_ut, l1.q_ut, l0.q_ut, r_m, r_p);
             s[P0][3] = phys::slope_minmod(l2.q_E, l1.q_E, l0.q_E, r_m, r_p);
             // interface is = cu-1 (ref :92-124): upwind donor cell and its slopes
-            const double disp = dt * fus2;
+            const T disp = dt * fus2;
             const bool up = disp > 0;
             const Upd& d = up ? l2 : l1;
-            const double Dxe = up ? -(dx - dt * fus3) : (dx + dt * fus1);
-            const double lf = Dxe / (2 * d.dxl);
-            const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
+            const T Dxe = up ? -(dx - dt * fus3) : (dx + dt * fus1);
+            const T lf = Dxe / (2 * d.dxl);
+            const T q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
             a[P0][0] = disp * (d.rho - (up ? s[P1][0] : s[P0][0]) * lf);
             a[P0][1] = disp * (q1 - (up ? s[P1][1] : s[P0][1]) * lf);
             a[P0][2] = disp * (q2 - (up ? s[P1][2] : s[P0][2]) * lf);
@@ -187,9 +188,9 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
             return project<Y_AXIS, P0>(l2);
         } else {
             // advection_first_order! at interface is = cu (ref src/projection_schemes.jl:62-78)
-            const double disp = dt * fus1;
+            const T disp = dt * fus1;
             const Upd& d = (disp > 0) ? l1 : l0;
-            const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
+            const T q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
             a[P0][0] = disp * d.rho;
             a[P0][1] = disp * q1;
             a[P0][2] = disp * q2;
@@ -200,18 +201,18 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 
     // euler_projection! of cell o with A_o = a[P1], A_{o+1} = a[P0] (ref src/projection_schemes.jl:23-41)
     template <bool Y_AXIS, int P0>
-    __device__ __forceinline__ Out4 project(const Upd& lo) const
+    __device__ __forceinline__ Out4<T> project(const Upd& lo) const
     {
         constexpr int P1 = P0 ^ 1;
-        const double dX = lo.dxl;
-        const double u = Y_AXIS ? lo.ut : lo.ua, v = Y_AXIS ? lo.ua : lo.ut;   // reference's (u, v)
-        const double t_rho  = (dX * lo.rho        - (a[P0][0] - a[P1][0])) / dx;
-        const double t_urho = (dX * lo.rho * u    - (a[P0][1] - a[P1][1])) / dx;
-        const double t_vrho = (dX * lo.rho * v    - (a[P0][2] - a[P1][2])) / dx;
-        const double t_Erho = (dX * lo.rho * lo.E - (a[P0][3] - a[P1][3])) / dx;
-        Out4 o;
+        const T dX = lo.dxl;
+        const T u = Y_AXIS ? lo.ut : lo.ua, v = Y_AXIS ? lo.ua : lo.ut;   // reference's (u, v)
+        const T t_rho  = (dX * lo.rho        - (a[P0][0] - a[P1][0])) / dx;
+        const T t_urho = (dX * lo.rho * u    - (a[P0][1] - a[P1][1])) / dx;
+        const T t_vrho = (dX * lo.rho * v    - (a[P0][2] - a[P1][2])) / dx;
+        const T t_Erho = (dX * lo.rho * lo.E - (a[P0][3] - a[P1][3])) / dx;
+        Out4<T> o;
         o.rho = t_rho;
-        const double un = t_urho / t_rho, vn = t_vrho / t_rho;
+        const T un = t_urho / t_rho, vn = t_vrho / t_rho;
         o.ua = Y_AXIS ? vn : un;
         o.ut = Y_AXIS ? un : vn;
         o.E = t_Erho / t_rho;
@@ -233,6 +234,7 @@ __device__ __forceinline__ double rcp(double x)
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
 }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32: 1 ulp
 
 // 1/x to ≈2e-15 (one Newton step): for the reciprocals that only feed second-order correction terms
 // (limited GAD ratios, θ, slope ratios), where a relative error of 1e-15 is far below their truncation error.
@@ -241,6 +243,7 @@ __device__ __forceinline__ double rcp1(double x)
     const double r = __builtin_amdgcn_rcp(x);
     return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
 }
+__device__ __forceinline__ float rcp1(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // sqrt(x) to ≈1-2 ulp: v_rsq_f64 + two coupled Newton (Goldschmidt) steps; sqrt(0) = 0.
 __device__ __forceinline__ double sqrt_(double x)
@@ -254,91 +257,100 @@ __device__ __forceinline__ double sqrt_(double x)
     g = __builtin_fma(g, r, g);
     return (x == 0.) ? 0. : g;
 }
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_sqrtf(x); }
 
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double max_(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double min_(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float min_(float a, float b) { return __builtin_fminf(a, b); }
 
-template <int LIM>
-__device__ __forceinline__ double limiter(double r)
+template <int LIM, typename T>
+__device__ __forceinline__ T limiter(T r)
 {
-    if (LIM == ARMON_LIMITER_MINMOD) return __builtin_fmax(0., __builtin_fmin(1., r));
-    if (LIM == ARMON_LIMITER_SUPERBEE)
-        return __builtin_fmax(__builtin_fmax(0., __builtin_fmin(2. * r, 1.)), __builtin_fmin(r, 2.));
-    return 1.;
+    if (LIM == ARMON_LIMITER_MINMOD) return max_(T(0.), min_(T(1.), r));
+    if (LIM == ARMON_LIMITER_SUPERBEE) return max_(max_(T(0.), min_(T(2.) * r, T(1.))), min_(r, T(2.)));
+    return T(1.);
 }
 
 // minmod(a, b) = sign·min(|a|,|b|) when a·b > 0, else 0  (== slope_minmod of ref projection_schemes.jl:15-20)
 // = the median of (a, b, 0).
-__device__ __forceinline__ double minmod(double a, double b)
+template <typename T>
+__device__ __forceinline__ T minmod(T a, T b)
 {
-    return __builtin_fmax(__builtin_fmin(a, b), __builtin_fmin(__builtin_fmax(a, b), 0.));
+    return max_(min_(a, b), min_(max_(a, b), T(0.)));
 }
 
 // ref src/kernels.jl:16-55 with the four divisions by (1 - s·x) and the two by ρ shared
-__device__ __forceinline__ void bizarrium(double rho, double ua, double ut, double E, double& p, double& cs)
+template <typename T>
+__device__ __forceinline__ void bizarrium(T rho, T ua, T ut, T E, T& p, T& cs)
 {
-    const double rho0 = 10000., K0 = 1e+11, Cv0 = 1000., T0 = 300., eps0 = 0., G0 = 1.5, s_ = 1.5;
-    const double q = -42080895. / 14941154., rr = 727668333. / 149411540.;
-    const double inv_rho = rcp(rho);
-    const double x = rho * (1. / rho0) - 1.;
-    const double G = G0 * (1. - rho0 * inv_rho);
-    const double x2 = x * x, x3 = x2 * x;
-    const double opx = 1. + x, opx2 = opx * opx, opx3 = opx2 * opx;
-    const double inv_d = rcp(1. - s_ * x);
-    const double f0 = (1. + (s_ / 3. - 2.) * x + q * x2 + rr * x3) * inv_d;
-    const double f1 = (s_ / 3. - 2. + 2. * q * x + 3. * rr * x2 + s_ * f0) * inv_d;
-    const double f2 = (2. * q + 6. * rr * x + 2. * s_ * f1) * inv_d;
-    const double epsk0 = eps0 - Cv0 * T0 * (1. + G) + 0.5 * (K0 / rho0) * x2 * f0;
-    const double pk0 = -Cv0 * T0 * G0 * rho0 + 0.5 * K0 * x * opx2 * (2. * f0 + x * f1);
-    const double pk0prime = -0.5 * K0 * opx3 * rho0 *
-                            (2. * (1. + 3. * x) * f0 + 2. * x * (2. + 3. * x) * f1 + x2 * opx * f2);
-    const double e = fma_(-0.5, fma_(ua, ua, ut * ut), E);
+    const T rho0 = T(10000.), K0 = T(1e+11), Cv0 = T(1000.), T0 = T(300.), eps0 = T(0.), G0 = T(1.5), s_ = T(1.5);
+    const T q = T(-42080895. / 14941154.), rr = T(727668333. / 149411540.);
+    const T inv_rho = rcp(rho);
+    const T x = rho * (T(1.) / rho0) - T(1.);
+    const T G = G0 * (T(1.) - rho0 * inv_rho);
+    const T x2 = x * x, x3 = x2 * x;
+    const T opx = T(1.) + x, opx2 = opx * opx, opx3 = opx2 * opx;
+    const T inv_d = rcp(T(1.) - s_ * x);
+    const T f0 = (T(1.) + (s_ / T(3.) - T(2.)) * x + q * x2 + rr * x3) * inv_d;
+    const T f1 = (s_ / T(3.) - T(2.) + T(2.) * q * x + T(3.) * rr * x2 + s_ * f0) * inv_d;
+    const T f2 = (T(2.) * q + T(6.) * rr * x + T(2.) * s_ * f1) * inv_d;
+    const T epsk0 = eps0 - Cv0 * T0 * (T(1.) + G) + T(0.5) * (K0 / rho0) * x2 * f0;
+    const T pk0 = -Cv0 * T0 * G0 * rho0 + T(0.5) * K0 * x * opx2 * (T(2.) * f0 + x * f1);
+    const T pk0prime = -T(0.5) * K0 * opx3 * rho0 *
+                            (T(2.) * (T(1.) + T(3.) * x) * f0 + T(2.) * x * (T(2.) + T(3.) * x) * f1 + x2 * opx * f2);
+    const T e = fma_(T(-0.5), fma_(ua, ua, ut * ut), E);
     p = pk0 + G0 * rho0 * (e - epsk0);
     cs = sqrt_(G0 * rho0 * (p - pk0) - pk0prime) * inv_rho;
 }
 
+
 }  // namespace fast
 
-template <int SCHEME, int LIM, int PROJ, int EOS>
+template <int SCHEME, int LIM, int PROJ, int EOS, typename T = double>
 struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
+    using real = T;
     using TR = PipeTraits<SCHEME, LIM, PROJ, EOS>;
     static constexpr int S = TR::S, W = TR::W, LAG = TR::LAG;
     static constexpr bool kExact = false;
 
-    struct Cell { double rho, ua, ut, E, p, rc; };
+    struct Cell { T rho, ua, ut, E, p, rc; };
     // Lagrangian state: q_* = ρ·(ua, ut, E); hinv = 0.5/dxl; d_* = q(this) - q(previous cell)
-    struct Upd { double rho, q_ua, q_ut, q_E, dxl, hinv, d_rho, d_ua, d_ut, d_E; };
+    struct Upd { T rho, q_ua, q_ut, q_E, dxl, hinv, d_rho, d_ua, d_ut, d_E; };
 
-    double dt, dx, gamma, inv_dx, dt_dx, gm1, ggm1;
+    T dt, dx, gamma, inv_dx, dt_dx, gm1, ggm1;
     Cell c[8];
-    double gus[4], gps[4], src[4];          // first-order solutions + (rc_l + rc_r) of the interface
-    double fps[4], dtu[4], pu[4];           // final flux: pˢ, dt·uˢ, pˢ·uˢ at interfaces nf .. nf-3
+    T gus[4], gps[4], src[4];          // first-order solutions + (rc_l + rc_r) of the interface
+    T fps[4], dtu[4], pu[4];           // final flux: pˢ, dt·uˢ, pˢ·uˢ at interfaces nf .. nf-3
     Upd l[4];
-    double isum[2];                         // 1 / (dxl[cu] + dxl[cu-1]) of this / the previous step
-    double s[2][4];
-    double a[2][4];
-    double csr[4];
+    T isum[2];                         // 1 / (dxl[cu] + dxl[cu-1]) of this / the previous step
+    T s[2][4];
+    T a[2][4];
+    T csr[4];
 
-    __device__ __forceinline__ PipeFast(double dt_, double dx_, double gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
+    __device__ __forceinline__ PipeFast(T dt_, T dx_, T gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
     {
-        inv_dx = 1. / dx_;
+        inv_dx = T(1.) / dx_;
         dt_dx = dt_ / dx_;
-        gm1 = gamma_ - 1.;
-        ggm1 = gamma_ * (gamma_ - 1.);
+        gm1 = gamma_ - T(1.);
+        ggm1 = gamma_ * (gamma_ - T(1.));
 #pragma unroll
-        for (int k = 0; k < 8; k++) c[k] = Cell{1., 0., 0., 1., 1., 1.};
+        for (int k = 0; k < 8; k++) c[k] = Cell{T(1.), T(0.), T(0.), T(1.), T(1.), T(1.)};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            gus[k] = 0.; gps[k] = 1.; src[k] = 2.;
-            fps[k] = 1.; dtu[k] = 0.; pu[k] = 0.; csr[k] = 1.;
-            l[k] = Upd{1., 0., 0., 1., dx_, 0.5 / dx_, 0., 0., 0., 0.};
-            s[0][k] = s[1][k] = 0.;
-            a[0][k] = a[1][k] = 0.;
+            gus[k] = T(0.); gps[k] = T(1.); src[k] = T(2.);
+            fps[k] = T(1.); dtu[k] = T(0.); pu[k] = T(0.); csr[k] = T(1.);
+            l[k] = Upd{T(1.), T(0.), T(0.), T(1.), dx_, T(0.5) / dx_, T(0.), T(0.), T(0.), T(0.)};
+            s[0][k] = s[1][k] = T(0.);
+            a[0][k] = a[1][k] = T(0.);
         }
-        isum[0] = isum[1] = 0.5 / dx_;
+        isum[0] = isum[1] = T(0.5) / dx_;
     }
 
     template <bool Y_AXIS, int PH8>
-    __device__ __forceinline__ Out4 push(double rho, double ua, double ut, double E, double& p_j, double& c_j, double& c_lag)
+    __device__ __forceinline__ Out4<T> push(T rho, T ua, T ut, T E, T& p_j, T& c_j, T& c_lag)
     {
         Cell& n = c[PH8 & 7];
         n.rho = rho; n.ua = ua; n.ut = ut; n.E = E;
@@ -346,7 +358,7 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     }
 
     template <bool Y_AXIS, int PH8>
-    __device__ __forceinline__ Out4 advance(double& p_j, double& c_j, double& c_lag)
+    __device__ __forceinline__ Out4<T> advance(T& p_j, T& c_j, T& c_lag)
     {
         using namespace fast;
         constexpr int PH = PH8 & 3;
@@ -358,12 +370,12 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         const Cell& c2 = c[(PH8 - 2) & 7];
 
         // ---- EOS
-        double p, cs;
+        T p, cs;
         if (EOS == ARMON_EOS_BIZARRIUM) {
             fast::bizarrium(c0.rho, c0.ua, c0.ut, c0.E, p, cs);
         } else {
             // p = (γ-1)ρe, c = sqrt(γp/ρ) = sqrt(γ(γ-1)e): no division
-            const double e = fma_(-0.5, fma_(c0.ua, c0.ua, c0.ut * c0.ut), c0.E);
+            const T e = fma_(T(-0.5), fma_(c0.ua, c0.ua, c0.ut * c0.ut), c0.E);
             p = gm1 * c0.rho * e;
             cs = sqrt_(ggm1 * e);
         }
@@ -375,26 +387,26 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 
         // ---- first-order acoustic solve at interface j: one shared reciprocal
         {
-            const double rc_l = c1.rc, rc_r = c0.rc;
-            const double sum = rc_l + rc_r;
-            const double inv = rcp(sum);
+            const T rc_l = c1.rc, rc_r = c0.rc;
+            const T sum = rc_l + rc_r;
+            const T inv = rcp(sum);
             src[R0] = sum;
             gus[R0] = fma_(rc_l, c1.ua, fma_(rc_r, c0.ua, c1.p - c0.p)) * inv;
             gps[R0] = fma_(rc_r, c1.p, fma_(rc_l, c0.p, rc_l * rc_r * (c1.ua - c0.ua))) * inv;
         }
 
         // ---- final flux at interface nf = j - S
-        double fus0;
+        T fus0;
         if (S == 1) {
-            const double gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
-            const double Au = gus1 - c2.ua, Bu = c1.ua - gus1;     // (uˢ_i - u[i-s]), (u[i] - uˢ_i)
-            const double Ap = gps1 - c2.p, Bp = c1.p - gps1;
-            const double r_um = limiter<LIM>((gus0 - c1.ua) * rcp1(Au + 1e-6));
-            const double r_pm = limiter<LIM>((gps0 - c1.p) * rcp1(Ap + 1e-6));
-            const double r_up = limiter<LIM>((c2.ua - gus2) * rcp1(Bu + 1e-6));
-            const double r_pp = limiter<LIM>((c2.p - gps2) * rcp1(Bp + 1e-6));
+            const T gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
+            const T Au = gus1 - c2.ua, Bu = c1.ua - gus1;     // (uˢ_i - u[i-s]), (u[i] - uˢ_i)
+            const T Ap = gps1 - c2.p, Bp = c1.p - gps1;
+            const T r_um = limiter<LIM>((gus0 - c1.ua) * rcp1(Au + T(1e-6)));
+            const T r_pm = limiter<LIM>((gps0 - c1.p) * rcp1(Ap + T(1e-6)));
+            const T r_up = limiter<LIM>((c2.ua - gus2) * rcp1(Bu + T(1e-6)));
+            const T r_pp = limiter<LIM>((c2.p - gps2) * rcp1(Bp + T(1e-6)));
             // θ = ½(1 - (rc_l+rc_r)/2 · dt/Dm), Dm = dx(ρ_l+ρ_r)/2  →  ½ - ½·(rc_l+rc_r)·(dt/dx)/(ρ_l+ρ_r)
-            const double theta = fma_(-0.5 * src[R1] * dt_dx, rcp1(c2.rho + c1.rho), 0.5);
+            const T theta = fma_(T(-0.5) * src[R1] * dt_dx, rcp1(c2.rho + c1.rho), T(0.5));
             fus0 = fma_(theta, fma_(r_up, Bu, -r_um * Au), gus1);
             fps[R0] = fma_(theta, fma_(r_pp, Bp, -r_pm * Ap), gps1);
         } else {
@@ -403,21 +415,21 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         }
         dtu[R0] = dt * fus0;
         pu[R0] = fps[R0] * fus0;
-        const double fps0 = fps[R0], fps1 = fps[R1];
+        const T fps0 = fps[R0], fps1 = fps[R1];
 
         // ---- Lagrangian update of cell cu = nf - 1
         {
             const Cell& cc = (S == 1) ? c2 : c1;
             Upd& n = l[R0];
             const Upd& prev = l[R1];
-            const double dtdm = dt_dx * rcp(cc.rho);             // dt / (ρ dx)
-            const double dxl = (dx + dtu[R0]) - dtu[R1];
-            const double inv_dxl = rcp(dxl);
+            const T dtdm = dt_dx * rcp(cc.rho);             // dt / (ρ dx)
+            const T dxl = (dx + dtu[R0]) - dtu[R1];
+            const T inv_dxl = rcp(dxl);
             n.dxl = dxl;
-            n.hinv = 0.5 * inv_dxl;
+            n.hinv = T(0.5) * inv_dxl;
             n.rho = cc.rho * dx * inv_dxl;
-            const double ua_n = fma_(dtdm, fps1 - fps0, cc.ua);
-            const double E_n = fma_(dtdm, pu[R1] - pu[R0], cc.E);
+            const T ua_n = fma_(dtdm, fps1 - fps0, cc.ua);
+            const T E_n = fma_(dtdm, pu[R1] - pu[R0], cc.E);
             n.q_ua = n.rho * ua_n;
             n.q_ut = n.rho * cc.ut;
             n.q_E = n.rho * E_n;
@@ -433,28 +445,28 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         if (W == 1) {
             // slopes of cell cu-1: r₊ = 2Δx/(Δx+Δx₊), r₋ = 2Δx/(Δx+Δx₋); the second sum is last step's first
             isum[P0] = rcp1(l1.dxl + l0.dxl);
-            const double two_dxl = 2. * l1.dxl;
-            const double r_p = two_dxl * isum[P0], r_m = two_dxl * isum[P1];
+            const T two_dxl = T(2.) * l1.dxl;
+            const T r_p = two_dxl * isum[P0], r_m = two_dxl * isum[P1];
             s[P0][0] = minmod(r_p * l0.d_rho, r_m * l1.d_rho);
             s[P0][Y_AXIS ? 2 : 1] = minmod(r_p * l0.d_ua, r_m * l1.d_ua);
             s[P0][Y_AXIS ? 1 : 2] = minmod(r_p * l0.d_ut, r_m * l1.d_ut);
             s[P0][3] = minmod(r_p * l0.d_E, r_m * l1.d_E);
             // interface is = cu-1
-            const double disp = dtu[R2];
+            const T disp = dtu[R2];
             const bool up = disp > 0;
             const Upd& d = up ? l2 : l1;
-            const double Dxe = up ? (dtu[R3] - dx) : (dx + dtu[R1]);
-            const double lf = Dxe * d.hinv;
-            const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
+            const T Dxe = up ? (dtu[R3] - dx) : (dx + dtu[R1]);
+            const T lf = Dxe * d.hinv;
+            const T q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
             a[P0][0] = disp * fma_(-(up ? s[P1][0] : s[P0][0]), lf, d.rho);
             a[P0][1] = disp * fma_(-(up ? s[P1][1] : s[P0][1]), lf, q1);
             a[P0][2] = disp * fma_(-(up ? s[P1][2] : s[P0][2]), lf, q2);
             a[P0][3] = disp * fma_(-(up ? s[P1][3] : s[P0][3]), lf, d.q_E);
             return project<Y_AXIS, P0>(l2);
         } else {
-            const double disp = dtu[R1];
+            const T disp = dtu[R1];
             const Upd& d = (disp > 0) ? l1 : l0;
-            const double q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
+            const T q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
             a[P0][0] = disp * d.rho;
             a[P0][1] = disp * q1;
             a[P0][2] = disp * q2;
@@ -465,20 +477,20 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
 
     // (dX·q - ΔA)/dx, then u = ρu/ρ …: the 1/dx cancels in the three ratios
     template <bool Y_AXIS, int P0>
-    __device__ __forceinline__ Out4 project(const Upd& lo) const
+    __device__ __forceinline__ Out4<T> project(const Upd& lo) const
     {
         using namespace fast;
         constexpr int P1 = P0 ^ 1;
-        const double dX = lo.dxl;
-        const double q1 = Y_AXIS ? lo.q_ut : lo.q_ua, q2 = Y_AXIS ? lo.q_ua : lo.q_ut;
-        const double T_rho = fma_(dX, lo.rho, a[P1][0] - a[P0][0]);
-        const double T_u = fma_(dX, q1, a[P1][1] - a[P0][1]);
-        const double T_v = fma_(dX, q2, a[P1][2] - a[P0][2]);
-        const double T_E = fma_(dX, lo.q_E, a[P1][3] - a[P0][3]);
-        const double inv = rcp(T_rho);
-        Out4 o;
+        const T dX = lo.dxl;
+        const T q1 = Y_AXIS ? lo.q_ut : lo.q_ua, q2 = Y_AXIS ? lo.q_ua : lo.q_ut;
+        const T T_rho = fma_(dX, lo.rho, a[P1][0] - a[P0][0]);
+        const T T_u = fma_(dX, q1, a[P1][1] - a[P0][1]);
+        const T T_v = fma_(dX, q2, a[P1][2] - a[P0][2]);
+        const T T_E = fma_(dX, lo.q_E, a[P1][3] - a[P0][3]);
+        const T inv = rcp(T_rho);
+        Out4<T> o;
         o.rho = T_rho * inv_dx;
-        const double un = T_u * inv, vn = T_v * inv;
+        const T un = T_u * inv, vn = T_v * inv;
         o.ua = Y_AXIS ? vn : un;
         o.ut = Y_AXIS ? un : vn;
         o.E = T_E * inv;

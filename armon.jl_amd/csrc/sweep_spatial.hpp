@@ -29,6 +29,10 @@ __device__ __forceinline__ double from_prev_lane(double x)
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float from_prev_lane(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));
+}
 
 // value of the next lane; lane 63 reads 0
 __device__ __forceinline__ double from_next_lane(double x)
@@ -38,35 +42,39 @@ __device__ __forceinline__ double from_next_lane(double x)
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float from_next_lane(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
+}
 
 // Per-lane strip of K consecutive cells with access to the cells just outside it.
-template <int K>
+template <int K, typename T>
 struct Strip {
-    double v[K];
-    __device__ __forceinline__ double& operator[](int k) { return v[k]; }
-    __device__ __forceinline__ double operator[](int k) const { return v[k]; }
+    T v[K];
+    __device__ __forceinline__ T& operator[](int k) { return v[k]; }
+    __device__ __forceinline__ T operator[](int k) const { return v[k]; }
 };
 
-template <int K>
+template <int K, typename T>
 struct Shifted {      // v[k-1] for k = 0..K-1 ("left") or v[k+1] ("right")
-    double v[K];
-    __device__ __forceinline__ double operator[](int k) const { return v[k]; }
+    T v[K];
+    __device__ __forceinline__ T operator[](int k) const { return v[k]; }
 };
 
-template <int K>
-__device__ __forceinline__ Shifted<K> left_of(const Strip<K>& s)
+template <int K, typename T>
+__device__ __forceinline__ Shifted<K, T> left_of(const Strip<K, T>& s)
 {
-    Shifted<K> r;
+    Shifted<K, T> r;
     r.v[0] = from_prev_lane(s.v[K - 1]);
 #pragma unroll
     for (int k = 1; k < K; k++) r.v[k] = s.v[k - 1];
     return r;
 }
 
-template <int K>
-__device__ __forceinline__ Shifted<K> right_of(const Strip<K>& s)
+template <int K, typename T>
+__device__ __forceinline__ Shifted<K, T> right_of(const Strip<K, T>& s)
 {
-    Shifted<K> r;
+    Shifted<K, T> r;
     r.v[K - 1] = from_next_lane(s.v[0]);
 #pragma unroll
     for (int k = 0; k < K - 1; k++) r.v[k] = s.v[k + 1];
@@ -75,13 +83,14 @@ __device__ __forceinline__ Shifted<K> right_of(const Strip<K>& s)
 
 // One X sweep of the K cells held by each lane. In: pre-sweep (ρ, u, v, E). Out: post-sweep state, valid
 // for the cells at least LAG cells away from both ends of the wave's strip; p/c: EOS of the cells.
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K>
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, typename T = double>
 struct SpatialSweep {
     using TR = PipeTraits<SCHEME, LIM, PROJ, EOS>;
     static constexpr int S = TR::S, W = TR::W, LAG = TR::LAG;
-    using S_ = Strip<K>;
+    using S_ = Strip<K, T>;
+    using Sh = Shifted<K, T>;
 
-    double dt, dx, gamma;
+    T dt, dx, gamma;
 
     __device__ __forceinline__ void run(const S_& rho, const S_& u, const S_& v, const S_& E,
                                         S_& o_rho, S_& o_u, S_& o_v, S_& o_E, S_& p, S_& cs) const
@@ -98,7 +107,7 @@ struct SpatialSweep {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (EOS == ARMON_EOS_BIZARRIUM) {
-                double g_unused;
+                T g_unused;
                 phys::bizarrium<false>(rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k], g_unused);
             } else {
                 phys::perfect_gas(gamma, rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k]);
@@ -106,29 +115,29 @@ struct SpatialSweep {
             rc.v[k] = rho[k] * cs[k];
         }
         // first-order solve on the low side of each cell (ref src/riemann_schemes.jl:21-30)
-        const Shifted<K> rcL = left_of(rc), uL = left_of(ua), pL = left_of(p);
+        const Sh rcL = left_of(rc), uL = left_of(ua), pL = left_of(p);
         S_ gus, gps;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const double rc_l = rcL[k], rc_r = rc[k];
+            const T rc_l = rcL[k], rc_r = rc[k];
             gus.v[k] = (rc_l * uL[k] + rc_r * ua[k] + (pL[k] - p[k])) / (rc_l + rc_r);
             gps.v[k] = (rc_r * pL[k] + rc_l * p[k] + rc_l * rc_r * (uL[k] - ua[k])) / (rc_l + rc_r);
         }
         S_ fus, fps;
         if (S == 1) {
             // acoustic_GAD! (ref src/riemann_schemes.jl:84-104): cells i-s = left, i = own
-            const Shifted<K> rhoL = left_of(rho);
-            const Shifted<K> gusL = left_of(gus), gpsL = left_of(gps), gusR = right_of(gus), gpsR = right_of(gps);
+            const Sh rhoL = left_of(rho);
+            const Sh gusL = left_of(gus), gpsL = left_of(gps), gusR = right_of(gus), gpsR = right_of(gps);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double r_um = phys::limiter<LIM>((gusR[k] - ua[k]) / (gus[k] - uL[k] + 1e-6));
-                const double r_pm = phys::limiter<LIM>((gpsR[k] - p[k]) / (gps[k] - pL[k] + 1e-6));
-                const double r_up = phys::limiter<LIM>((uL[k] - gusL[k]) / (ua[k] - gus[k] + 1e-6));
-                const double r_pp = phys::limiter<LIM>((pL[k] - gpsL[k]) / (p[k] - gps[k] + 1e-6));
-                const double dm_l = rhoL[k] * dx;
-                const double dm_r = rho[k] * dx;
-                const double Dm = (dm_l + dm_r) / 2;
-                const double theta = 0.5 * (1 - (rcL[k] + rc[k]) / 2 * (dt / Dm));
+                const T r_um = phys::limiter<LIM>((gusR[k] - ua[k]) / (gus[k] - uL[k] + T(1e-6)));
+                const T r_pm = phys::limiter<LIM>((gpsR[k] - p[k]) / (gps[k] - pL[k] + T(1e-6)));
+                const T r_up = phys::limiter<LIM>((uL[k] - gusL[k]) / (ua[k] - gus[k] + T(1e-6)));
+                const T r_pp = phys::limiter<LIM>((pL[k] - gpsL[k]) / (p[k] - gps[k] + T(1e-6)));
+                const T dm_l = rhoL[k] * dx;
+                const T dm_r = rho[k] * dx;
+                const T Dm = (dm_l + dm_r) / 2;
+                const T theta = T(0.5) * (1 - (rcL[k] + rc[k]) / 2 * (dt / Dm));
                 fus.v[k] = gus[k] + theta * (r_up * (ua[k] - gus[k]) - r_um * (gus[k] - uL[k]));
                 fps.v[k] = gps[k] + theta * (r_pp * (p[k] - gps[k]) - r_pm * (gps[k] - pL[k]));
             }
@@ -137,11 +146,11 @@ struct SpatialSweep {
             fps = gps;
         }
         // Lagrangian update (ref src/kernels.jl:58-68)
-        const Shifted<K> fusR = right_of(fus), fpsR = right_of(fps);
+        const Sh fusR = right_of(fus), fpsR = right_of(fps);
         S_ l_rho, l_ua, l_E, dxl, q_ua, q_ut, q_E;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const double dm = rho[k] * dx;
+            const T dm = rho[k] * dx;
             dxl.v[k] = dx + dt * (fusR[k] - fus[k]);
             l_rho.v[k] = dm / dxl[k];
             l_ua.v[k] = ua[k] + dt / dm * (fps[k] - fpsR[k]);
@@ -152,28 +161,28 @@ struct SpatialSweep {
         }
         // advection flux on the low side of each cell
         S_ a0, a1, a2, a3;    // ρ, ρu, ρv, ρE
-        const Shifted<K> rL = left_of(l_rho), quL = left_of(q_ua), qvL = left_of(q_ut), qEL = left_of(q_E);
+        const Sh rL = left_of(l_rho), quL = left_of(q_ua), qvL = left_of(q_ut), qEL = left_of(q_E);
         if (W == 1) {
-            const Shifted<K> rR = right_of(l_rho), quR = right_of(q_ua), qvR = right_of(q_ut), qER = right_of(q_E);
-            const Shifted<K> dxlL = left_of(dxl), dxlR = right_of(dxl);
+            const Sh rR = right_of(l_rho), quR = right_of(q_ua), qvR = right_of(q_ut), qER = right_of(q_E);
+            const Sh dxlL = left_of(dxl), dxlR = right_of(dxl);
             S_ s0, s1, s2, s3;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double r_m = (2 * dxl[k]) / (dxl[k] + dxlL[k]);
-                const double r_p = (2 * dxl[k]) / (dxl[k] + dxlR[k]);
+                const T r_m = (2 * dxl[k]) / (dxl[k] + dxlL[k]);
+                const T r_p = (2 * dxl[k]) / (dxl[k] + dxlR[k]);
                 s0.v[k] = phys::slope_minmod(rL[k], l_rho[k], rR[k], r_m, r_p);
                 s1.v[k] = phys::slope_minmod(quL[k], q_ua[k], quR[k], r_m, r_p);
                 s2.v[k] = phys::slope_minmod(qvL[k], q_ut[k], qvR[k], r_m, r_p);
                 s3.v[k] = phys::slope_minmod(qEL[k], q_E[k], qER[k], r_m, r_p);
             }
-            const Shifted<K> s0L = left_of(s0), s1L = left_of(s1), s2L = left_of(s2), s3L = left_of(s3);
-            const Shifted<K> fusL = left_of(fus);
+            const Sh s0L = left_of(s0), s1L = left_of(s1), s2L = left_of(s2), s3L = left_of(s3);
+            const Sh fusL = left_of(fus);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double disp = dt * fus[k];
+                const T disp = dt * fus[k];
                 const bool up = disp > 0;
-                const double Dxe = up ? -(dx - dt * fusL[k]) : (dx + dt * fusR[k]);
-                const double lf = Dxe / (2 * (up ? dxlL[k] : dxl[k]));
+                const T Dxe = up ? -(dx - dt * fusL[k]) : (dx + dt * fusR[k]);
+                const T lf = Dxe / (2 * (up ? dxlL[k] : dxl[k]));
                 a0.v[k] = disp * ((up ? rL[k] : l_rho[k]) - (up ? s0L[k] : s0[k]) * lf);
                 a1.v[k] = disp * ((up ? quL[k] : q_ua[k]) - (up ? s1L[k] : s1[k]) * lf);
                 a2.v[k] = disp * ((up ? qvL[k] : q_ut[k]) - (up ? s2L[k] : s2[k]) * lf);
@@ -182,7 +191,7 @@ struct SpatialSweep {
         } else {
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double disp = dt * fus[k];
+                const T disp = dt * fus[k];
                 const bool up = disp > 0;
                 a0.v[k] = disp * (up ? rL[k] : l_rho[k]);
                 a1.v[k] = disp * (up ? quL[k] : q_ua[k]);
@@ -191,14 +200,14 @@ struct SpatialSweep {
             }
         }
         // projection (ref src/projection_schemes.jl:23-41)
-        const Shifted<K> a0R = right_of(a0), a1R = right_of(a1), a2R = right_of(a2), a3R = right_of(a3);
+        const Sh a0R = right_of(a0), a1R = right_of(a1), a2R = right_of(a2), a3R = right_of(a3);
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const double dX = dxl[k];
-            const double t_rho  = (dX * l_rho[k]           - (a0R[k] - a0[k])) / dx;
-            const double t_urho = (dX * l_rho[k] * l_ua[k] - (a1R[k] - a1[k])) / dx;
-            const double t_vrho = (dX * l_rho[k] * ut[k]   - (a2R[k] - a2[k])) / dx;
-            const double t_Erho = (dX * l_rho[k] * l_E[k]  - (a3R[k] - a3[k])) / dx;
+            const T dX = dxl[k];
+            const T t_rho  = (dX * l_rho[k]           - (a0R[k] - a0[k])) / dx;
+            const T t_urho = (dX * l_rho[k] * l_ua[k] - (a1R[k] - a1[k])) / dx;
+            const T t_vrho = (dX * l_rho[k] * ut[k]   - (a2R[k] - a2[k])) / dx;
+            const T t_Erho = (dX * l_rho[k] * l_E[k]  - (a3R[k] - a3[k])) / dx;
             o_rho.v[k] = t_rho;
             o_u.v[k] = t_urho / t_rho;
             o_v.v[k] = t_vrho / t_rho;
@@ -211,42 +220,42 @@ struct SpatialSweep {
                                              S_& o_rho, S_& o_u, S_& o_v, S_& o_E, S_& p, S_& cs) const
     {
         using namespace fast;
-        const double inv_dx = 1. / dx, dt_dx = dt / dx, gm1 = gamma - 1., ggm1 = gamma * (gamma - 1.);
+        const T inv_dx = T(1.) / dx, dt_dx = dt / dx, gm1 = gamma - T(1.), ggm1 = gamma * (gamma - T(1.));
         S_ rc;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (EOS == ARMON_EOS_BIZARRIUM) {
                 fast::bizarrium(rho[k], ua[k], ut[k], E[k], p.v[k], cs.v[k]);
             } else {
-                const double e = fma_(-0.5, fma_(ua[k], ua[k], ut[k] * ut[k]), E[k]);
+                const T e = fma_(T(-0.5), fma_(ua[k], ua[k], ut[k] * ut[k]), E[k]);
                 p.v[k] = gm1 * rho[k] * e;
                 cs.v[k] = sqrt_(ggm1 * e);
             }
             rc.v[k] = rho[k] * cs[k];
         }
-        const Shifted<K> rcL = left_of(rc), uL = left_of(ua), pL = left_of(p);
+        const Sh rcL = left_of(rc), uL = left_of(ua), pL = left_of(p);
         S_ gus, gps, src;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const double rc_l = rcL[k], rc_r = rc[k];
+            const T rc_l = rcL[k], rc_r = rc[k];
             src.v[k] = rc_l + rc_r;
-            const double inv = rcp(src[k]);
+            const T inv = rcp(src[k]);
             gus.v[k] = fma_(rc_l, uL[k], fma_(rc_r, ua[k], pL[k] - p[k])) * inv;
             gps.v[k] = fma_(rc_r, pL[k], fma_(rc_l, p[k], rc_l * rc_r * (uL[k] - ua[k]))) * inv;
         }
         S_ fus, fps;
         if (S == 1) {
-            const Shifted<K> rhoL = left_of(rho);
-            const Shifted<K> gusL = left_of(gus), gpsL = left_of(gps), gusR = right_of(gus), gpsR = right_of(gps);
+            const Sh rhoL = left_of(rho);
+            const Sh gusL = left_of(gus), gpsL = left_of(gps), gusR = right_of(gus), gpsR = right_of(gps);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double Au = gus[k] - uL[k], Bu = ua[k] - gus[k];
-                const double Ap = gps[k] - pL[k], Bp = p[k] - gps[k];
-                const double r_um = limiter<LIM>((gusR[k] - ua[k]) * rcp1(Au + 1e-6));
-                const double r_pm = limiter<LIM>((gpsR[k] - p[k]) * rcp1(Ap + 1e-6));
-                const double r_up = limiter<LIM>((uL[k] - gusL[k]) * rcp1(Bu + 1e-6));
-                const double r_pp = limiter<LIM>((pL[k] - gpsL[k]) * rcp1(Bp + 1e-6));
-                const double theta = fma_(-0.5 * src[k] * dt_dx, rcp1(rhoL[k] + rho[k]), 0.5);
+                const T Au = gus[k] - uL[k], Bu = ua[k] - gus[k];
+                const T Ap = gps[k] - pL[k], Bp = p[k] - gps[k];
+                const T r_um = limiter<LIM>((gusR[k] - ua[k]) * rcp1(Au + T(1e-6)));
+                const T r_pm = limiter<LIM>((gpsR[k] - p[k]) * rcp1(Ap + T(1e-6)));
+                const T r_up = limiter<LIM>((uL[k] - gusL[k]) * rcp1(Bu + T(1e-6)));
+                const T r_pp = limiter<LIM>((pL[k] - gpsL[k]) * rcp1(Bp + T(1e-6)));
+                const T theta = fma_(T(-0.5) * src[k] * dt_dx, rcp1(rhoL[k] + rho[k]), T(0.5));
                 fus.v[k] = fma_(theta, fma_(r_up, Bu, -r_um * Au), gus[k]);
                 fps.v[k] = fma_(theta, fma_(r_pp, Bp, -r_pm * Ap), gps[k]);
             }
@@ -260,45 +269,45 @@ struct SpatialSweep {
             dtu.v[k] = dt * fus[k];
             pu.v[k] = fps[k] * fus[k];
         }
-        const Shifted<K> dtuR = right_of(dtu), fpsR = right_of(fps), puR = right_of(pu);
+        const Sh dtuR = right_of(dtu), fpsR = right_of(fps), puR = right_of(pu);
         S_ l_rho, dxl, hinv, q_ua, q_ut, q_E;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const double dtdm = dt_dx * rcp(rho[k]);
+            const T dtdm = dt_dx * rcp(rho[k]);
             dxl.v[k] = (dx + dtuR[k]) - dtu[k];
-            const double inv_dxl = rcp(dxl[k]);
-            hinv.v[k] = 0.5 * inv_dxl;
+            const T inv_dxl = rcp(dxl[k]);
+            hinv.v[k] = T(0.5) * inv_dxl;
             l_rho.v[k] = rho[k] * dx * inv_dxl;
-            const double ua_n = fma_(dtdm, fps[k] - fpsR[k], ua[k]);
-            const double E_n = fma_(dtdm, pu[k] - puR[k], E[k]);
+            const T ua_n = fma_(dtdm, fps[k] - fpsR[k], ua[k]);
+            const T E_n = fma_(dtdm, pu[k] - puR[k], E[k]);
             q_ua.v[k] = l_rho[k] * ua_n;
             q_ut.v[k] = l_rho[k] * ut[k];
             q_E.v[k] = l_rho[k] * E_n;
         }
         S_ a0, a1, a2, a3;
-        const Shifted<K> rL = left_of(l_rho), quL = left_of(q_ua), qvL = left_of(q_ut), qEL = left_of(q_E);
+        const Sh rL = left_of(l_rho), quL = left_of(q_ua), qvL = left_of(q_ut), qEL = left_of(q_E);
         if (W == 1) {
-            const Shifted<K> rR = right_of(l_rho), quR = right_of(q_ua), qvR = right_of(q_ut), qER = right_of(q_E);
-            const Shifted<K> dxlL = left_of(dxl), dxlR = right_of(dxl);
+            const Sh rR = right_of(l_rho), quR = right_of(q_ua), qvR = right_of(q_ut), qER = right_of(q_E);
+            const Sh dxlL = left_of(dxl), dxlR = right_of(dxl);
             S_ s0, s1, s2, s3;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double two_dxl = 2. * dxl[k];
-                const double r_m = two_dxl * rcp1(dxl[k] + dxlL[k]);
-                const double r_p = two_dxl * rcp1(dxl[k] + dxlR[k]);
+                const T two_dxl = T(2.) * dxl[k];
+                const T r_m = two_dxl * rcp1(dxl[k] + dxlL[k]);
+                const T r_p = two_dxl * rcp1(dxl[k] + dxlR[k]);
                 s0.v[k] = minmod(r_p * (rR[k] - l_rho[k]), r_m * (l_rho[k] - rL[k]));
                 s1.v[k] = minmod(r_p * (quR[k] - q_ua[k]), r_m * (q_ua[k] - quL[k]));
                 s2.v[k] = minmod(r_p * (qvR[k] - q_ut[k]), r_m * (q_ut[k] - qvL[k]));
                 s3.v[k] = minmod(r_p * (qER[k] - q_E[k]), r_m * (q_E[k] - qEL[k]));
             }
-            const Shifted<K> s0L = left_of(s0), s1L = left_of(s1), s2L = left_of(s2), s3L = left_of(s3);
-            const Shifted<K> dtuL = left_of(dtu), hinvL = left_of(hinv);
+            const Sh s0L = left_of(s0), s1L = left_of(s1), s2L = left_of(s2), s3L = left_of(s3);
+            const Sh dtuL = left_of(dtu), hinvL = left_of(hinv);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double disp = dtu[k];
+                const T disp = dtu[k];
                 const bool up = disp > 0;
-                const double Dxe = up ? (dtuL[k] - dx) : (dx + dtuR[k]);
-                const double lf = Dxe * (up ? hinvL[k] : hinv[k]);
+                const T Dxe = up ? (dtuL[k] - dx) : (dx + dtuR[k]);
+                const T lf = Dxe * (up ? hinvL[k] : hinv[k]);
                 a0.v[k] = disp * fma_(-(up ? s0L[k] : s0[k]), lf, up ? rL[k] : l_rho[k]);
                 a1.v[k] = disp * fma_(-(up ? s1L[k] : s1[k]), lf, up ? quL[k] : q_ua[k]);
                 a2.v[k] = disp * fma_(-(up ? s2L[k] : s2[k]), lf, up ? qvL[k] : q_ut[k]);
@@ -307,7 +316,7 @@ struct SpatialSweep {
         } else {
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const double disp = dtu[k];
+                const T disp = dtu[k];
                 const bool up = disp > 0;
                 a0.v[k] = disp * (up ? rL[k] : l_rho[k]);
                 a1.v[k] = disp * (up ? quL[k] : q_ua[k]);
@@ -315,15 +324,15 @@ struct SpatialSweep {
                 a3.v[k] = disp * (up ? qEL[k] : q_E[k]);
             }
         }
-        const Shifted<K> a0R = right_of(a0), a1R = right_of(a1), a2R = right_of(a2), a3R = right_of(a3);
+        const Sh a0R = right_of(a0), a1R = right_of(a1), a2R = right_of(a2), a3R = right_of(a3);
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const double dX = dxl[k];
-            const double T_rho = fma_(dX, l_rho[k], a0[k] - a0R[k]);
-            const double T_u = fma_(dX, q_ua[k], a1[k] - a1R[k]);
-            const double T_v = fma_(dX, q_ut[k], a2[k] - a2R[k]);
-            const double T_E = fma_(dX, q_E[k], a3[k] - a3R[k]);
-            const double inv = rcp(T_rho);
+            const T dX = dxl[k];
+            const T T_rho = fma_(dX, l_rho[k], a0[k] - a0R[k]);
+            const T T_u = fma_(dX, q_ua[k], a1[k] - a1R[k]);
+            const T T_v = fma_(dX, q_ut[k], a2[k] - a2R[k]);
+            const T T_E = fma_(dX, q_E[k], a3[k] - a3R[k]);
+            const T inv = rcp(T_rho);
             o_rho.v[k] = T_rho * inv_dx;
             o_u.v[k] = T_u * inv;
             o_v.v[k] = T_v * inv;

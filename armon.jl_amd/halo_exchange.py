@@ -46,11 +46,13 @@ class HaloExchanger:
             if params.neighbours[side] == PROC_NULL:
                 continue
             n = bs.real_face_size(side) * bs.ghosts * max_vars       # ref src/blocking/block_grid.jl:134-138
+            tdt = torch.float32 if params.data_type == np.float32 else torch.float64
+            self.tdt = tdt
             if host_arrays is not None:
-                mk = lambda: torch.zeros(n, dtype=torch.float64)
+                mk = lambda: torch.zeros(n, dtype=tdt)
             else:
                 dev = torch.device("cuda", params.device_id)
-                mk = lambda: torch.zeros(n, dtype=torch.float64, device=dev)
+                mk = lambda: torch.zeros(n, dtype=tdt, device=dev)
             self.buf[side] = (mk(), mk())                            # (send, recv)
 
     # -- pack / unpack ---------------------------------------------------------------------------------
@@ -66,7 +68,7 @@ class HaloExchanger:
         if self.host_arrays is not None:
             _host_pack(dom, bs.ghosts, face, send.numpy(), [self.host_arrays[k] for k in names], True)
             return
-        check(_lib.lib().armon_hip_pack_to_array(p.device.ctx, dom, bs.ghosts, face, C.c_void_p(send.data_ptr()),
+        check(p.fn("pack_to_array")(p.device.ctx, dom, bs.ghosts, face, C.c_void_p(send.data_ptr()),
                                                  len(names), self._vars_ptrs(names)))
 
     def unpack(self, side, names):
@@ -77,7 +79,7 @@ class HaloExchanger:
         if self.host_arrays is not None:
             _host_pack(dom, bs.ghosts, face, recv.numpy(), [self.host_arrays[k] for k in names], False)
             return
-        check(_lib.lib().armon_hip_unpack_from_array(p.device.ctx, dom, bs.ghosts, face, C.c_void_p(recv.data_ptr()),
+        check(p.fn("unpack_from_array")(p.device.ctx, dom, bs.ghosts, face, C.c_void_p(recv.data_ptr()),
                                                      len(names), self._vars_ptrs(names)))
 
     # -- exchange ---------------------------------------------------------------------------------------
@@ -99,7 +101,7 @@ class HaloExchanger:
             n = bs.real_face_size(s) * bs.ghosts * len(names)
             send, recv = self.buf[s][0][:n], self.buf[s][1][:n]
             if not self.device_buffers and self.host_arrays is None:
-                staged[s] = (send.cpu(), torch.empty(n, dtype=torch.float64))   # host staging (gpu_aware=false)
+                staged[s] = (send.cpu(), torch.empty(n, dtype=self.tdt))   # host staging (gpu_aware=false)
                 send, recv = staged[s]
             peer = p.neighbours[s]
             ops.append(dist.P2POp(dist.isend, send, peer, self.group, tag=int(s)))

@@ -24,8 +24,10 @@ PROC_NULL = -1
 class ArmonParameters:
     def __init__(self, *, data_type=np.float64, N=(10, 10), **options):
         self.data_type = np.dtype(data_type)
-        if self.data_type != np.float64:
-            solver_error("config", "the HIP backend currently implements data_type=Float64 only")
+        if self.data_type not in (np.dtype(np.float64), np.dtype(np.float32)):
+            solver_error("config", f"unsupported data_type {data_type}: Float64 or Float32")
+        self.T = self.data_type.type          # scalar constructor: host-side arithmetic is done in T, like the reference
+        self.suffix = "_f32" if self.data_type == np.float32 else ""
         if len(N) != 2:
             solver_error("config", "only 2-D domains are supported")
         self.N = tuple(int(n) for n in N)
@@ -105,8 +107,9 @@ class ArmonParameters:
         if origin is None:
             origin = default_domain_origin(name)
         self.origin = tuple(float(o) for o in origin)
-        dX = (self.domain_size[0] / self.N[0], self.domain_size[1] / self.N[1])
-        self.test = create_test(name, dX)
+        T = self.T
+        dX = (T(self.domain_size[0]) / T(self.N[0]), T(self.domain_size[1]) / T(self.N[1]))
+        self.test = create_test(name, dX, T)
         self.maxcycle = int(maxcycle)
         self.cfl = float(cfl) if cfl != 0 else self.test.cfl
         self.maxtime = float(maxtime) if maxtime != 0 else self.test.maxtime
@@ -230,6 +233,15 @@ class ArmonParameters:
             from .device import HIPDevice
             self._device = HIPDevice(self.device_id, self._stream)
         return self._device
+
+    def fn(self, name):
+        """The C-ABI entry point ``armon_hip_<name>`` for this run's data_type (``_f32`` suffix for Float32)."""
+        from . import _lib
+        return getattr(_lib.lib(), "armon_hip_" + name + self.suffix)
+
+    def cell_size(self, i_ax):
+        """Global cell size along an axis, computed in T (ref src/solver_state.jl:341, src/reductions.jl:92)."""
+        return self.T(self.domain_size[i_ax]) / self.T(self.global_grid[i_ax])
 
     def wait(self):
         """``Base.wait(params)`` (ref src/parameters.jl:1031-1038)."""

@@ -43,7 +43,8 @@ class SolverStats:   # ref src/solver.jl:13-23
 
 
 class GlobalTimeStep:
-    """ref src/solver_state.jl:30-166 — cycle/time/dt with the reference's one-cycle lag."""
+    """ref src/solver_state.jl:30-166 — cycle/time/dt with the reference's one-cycle lag. All arithmetic is
+    done in the run's data type T (numpy scalars), like the reference's ``GlobalTimeStep{T}``."""
 
     def __init__(self, params):
         self.params = params
@@ -51,21 +52,25 @@ class GlobalTimeStep:
 
     def reset(self):   # ref :58-68
         p = self.params
+        T = p.T
         self.cycle = 0
-        self.time = 0.
-        self.current_dt = p.Dt if p.cst_dt else 0.
-        self.next_cycle_dt = math.inf
+        self.time = T(0.)
+        self.current_dt = T(p.Dt) if p.cst_dt else T(0.)
+        self.next_cycle_dt = T(math.inf)
 
     def update_dt(self, new_dt):
         """ref update_dt!, :102-142 (``new_dt`` = global minimum of the local CFL time steps)."""
         p = self.params
+        T = p.T
+        new_dt = T(new_dt)
         previous_dt = self.current_dt
         if not math.isfinite(new_dt) or new_dt <= 0:
             solver_error("time", f"Invalid time step for cycle {self.cycle}: {new_dt}")
         elif previous_dt == 0:
-            new_dt = p.cfl * new_dt
+            new_dt = T(p.cfl) * new_dt
         else:
-            new_dt = min(p.cfl * new_dt, 1.05 * previous_dt)
+            # convert(T, min(cfl·new_dt, 1.05·previous_dt)) with the 1.05 product in Float64 (ref :129)
+            new_dt = T(min(float(T(p.cfl) * new_dt), 1.05 * float(previous_dt)))
         self.next_cycle_dt = new_dt
         if self.current_dt == 0:
             self.current_dt = self.next_cycle_dt
@@ -73,13 +78,14 @@ class GlobalTimeStep:
     def next_cycle(self):
         """ref next_cycle!, :145-166"""
         p = self.params
+        T = p.T
         self.cycle += 1
-        self.time += self.current_dt
+        self.time = T(self.time + self.current_dt)
         if p.cst_dt:
-            self.current_dt = self.next_cycle_dt = p.Dt
+            self.current_dt = self.next_cycle_dt = T(p.Dt)
             return
         self.current_dt = self.next_cycle_dt
-        self.next_cycle_dt = math.inf
+        self.next_cycle_dt = T(math.inf)
 
 
 def split_axes(splitting, cycle):
@@ -109,10 +115,11 @@ class BlockGrid:
         self.size = params.block_size
         dev = params.device
         n = self.size.n_cells
-        self.data = {f: dev.empty(n) for f in FIELDS}
-        self.alt = {f: dev.empty(n) for f in STATE_VARS} if params.use_fused_sweep else None
+        dt_ = params.data_type
+        self.data = {f: dev.empty(n, dt_) for f in FIELDS}
+        self.alt = {f: dev.empty(n, dt_) for f in STATE_VARS} if params.use_fused_sweep else None
         self.global_dt = GlobalTimeStep(params)
-        self.dt_scalar = dev.zeros(2)          # device scalar written by the fused dt reduction
+        self.dt_scalar = dev.zeros(2, dt_)     # device scalar written by the fused dt reduction
         self.dt_pending = False                # True when dt_scalar holds the CFL step of the current state
         self.comm = None                       # set by halo_exchange.setup when use_MPI
 
@@ -145,7 +152,7 @@ class BlockGrid:
         return a.reshape(self.size.size[1], self.size.size[0])[g:g + ny, g:g + nx]
 
     def memory_required(self):
-        n = self.size.n_cells * 8
+        n = self.size.n_cells * self.params.data_type.itemsize
         return n * (16 + (4 if self.alt else 0))
 
 
@@ -189,11 +196,11 @@ def init_test(params, grid):
     full = params.steps_ranges[Axis.X].full_domain
     gpos = (C.c_int64 * 2)(params.N_origin[0] - 1, params.N_origin[1] - 1)
     gN = (C.c_int64 * 2)(*params.global_grid)
-    origin = (C.c_double * 2)(*params.origin)
-    dX = (C.c_double * 2)(params.domain_size[0] / params.global_grid[0],
-                          params.domain_size[1] / params.global_grid[1])
+    real = C.c_float if params.data_type == np.float32 else C.c_double
+    origin = (real * 2)(*params.origin)
+    dX = (real * 2)(params.cell_size(0), params.cell_size(1))
     bd = grid.block_data_ptrs()
-    check(_L().armon_hip_init_test(params.device.ctx, _range(params, full), params.test.tag,
+    check(params.fn("init_test")(params.device.ctx, _range(params, full), params.test.tag,
                                    bs.size[0], bs.size[1], bs.ghosts, C.byref(gpos), C.byref(gN),
                                    C.byref(origin), C.byref(dX), params.test.r, C.byref(bd)))
 
@@ -204,11 +211,11 @@ def update_EOS(params, grid, axis=Axis.X):
     p = grid.ptr
     if params.test.eos == "bizarrium":
         with _k(params, "bizarrium_EOS"):
-            check(_L().armon_hip_bizarrium_EOS(params.device.ctx, r, p("rho"), p("u"), p("v"), p("E"),
+            check(params.fn("bizarrium_EOS")(params.device.ctx, r, p("rho"), p("u"), p("v"), p("E"),
                                                p("p"), p("c"), p("g")))
     else:
         with _k(params, "perfect_gas_EOS"):
-            check(_L().armon_hip_perfect_gas_EOS(params.device.ctx, r, params.test.gamma, p("rho"), p("E"),
+            check(params.fn("perfect_gas_EOS")(params.device.ctx, r, params.test.gamma, p("rho"), p("E"),
                                                  p("u"), p("v"), p("p"), p("c"), p("g")))
 
 
@@ -221,7 +228,7 @@ def boundary_conditions(params, grid, axis, side):
     if side in (Side.Left, Side.Bottom):
         incr = -incr
     p = grid.ptr
-    check(_L().armon_hip_boundary_conditions(params.device.ctx, domain, incr, bs.ghosts, uf, vf,
+    check(params.fn("boundary_conditions")(params.device.ctx, domain, incr, bs.ghosts, uf, vf,
                                              p("rho"), p("u"), p("v"), p("p"), p("c"), p("g"), p("E")))
 
 
@@ -244,11 +251,11 @@ def numerical_fluxes(params, grid, axis, dt, dx):
     ua = p("u") if axis == Axis.X else p("v")
     if params.riemann_scheme == "GAD":
         with _k(params, "acoustic_GAD"):
-            check(_L().armon_hip_acoustic_GAD(params.device.ctx, r, s, dt, dx, p("us"), p("ps"), p("rho"), ua,
+            check(params.fn("acoustic_GAD")(params.device.ctx, r, s, dt, dx, p("us"), p("ps"), p("rho"), ua,
                                               p("p"), p("c"), LIMITERS[params.riemann_limiter]))
     else:
         with _k(params, "acoustic"):
-            check(_L().armon_hip_acoustic(params.device.ctx, r, s, p("us"), p("ps"), p("rho"), ua, p("p"), p("c")))
+            check(params.fn("acoustic")(params.device.ctx, r, s, p("us"), p("ps"), p("rho"), ua, p("p"), p("c")))
 
 
 def cell_update(params, grid, axis, dt, dx):
@@ -258,7 +265,7 @@ def cell_update(params, grid, axis, dt, dx):
     p = grid.ptr
     ua = p("u") if axis == Axis.X else p("v")
     with _k(params, "cell_update"):
-        check(_L().armon_hip_cell_update(params.device.ctx, r, s, dx, dt, p("us"), p("ps"), p("rho"), ua, p("E")))
+        check(params.fn("cell_update")(params.device.ctx, r, s, dx, dt, p("us"), p("ps"), p("rho"), ua, p("E")))
 
 
 def projection_remap(params, grid, axis, dt, dx):
@@ -269,36 +276,35 @@ def projection_remap(params, grid, axis, dt, dx):
     w = (p("work_1"), p("work_2"), p("work_3"), p("work_4"))
     if params.projection_scheme == "euler_2nd":
         with _k(params, "advection_second_order"):
-            check(_L().armon_hip_advection_second_order(params.device.ctx, ra, s, dx, dt, p("us"), p("rho"),
+            check(params.fn("advection_second_order")(params.device.ctx, ra, s, dx, dt, p("us"), p("rho"),
                                                         p("u"), p("v"), p("E"), *w))
     else:
         with _k(params, "advection_first_order"):
-            check(_L().armon_hip_advection_first_order(params.device.ctx, ra, s, dt, p("us"), p("rho"),
+            check(params.fn("advection_first_order")(params.device.ctx, ra, s, dt, p("us"), p("rho"),
                                                        p("u"), p("v"), p("E"), *w))
     rp = _range(params, params.steps_ranges[axis].projection)
     with _k(params, "euler_projection"):
-        check(_L().armon_hip_euler_projection(params.device.ctx, rp, s, dx, dt, p("us"), p("rho"), p("u"),
+        check(params.fn("euler_projection")(params.device.ctx, rp, s, dx, dt, p("us"), p("rho"), p("u"),
                                               p("v"), p("E"), *w))
 
 
 def local_time_step(params, grid):
     """ref src/reductions.jl:89-110 (dx, dy are the GLOBAL cell sizes, :92)"""
     r = _range(params, params.steps_ranges[Axis.X].real_domain)
-    dx = params.domain_size[0] / params.global_grid[0]
-    dy = params.domain_size[1] / params.global_grid[1]
-    out = C.c_double()
+    dx, dy = params.cell_size(0), params.cell_size(1)
+    out = (C.c_float if params.data_type == np.float32 else C.c_double)()
     p = grid.ptr
     with _k(params, "dtCFL"):
-        check(_L().armon_hip_dtCFL(params.device.ctx, r, dx, dy, p("u"), p("v"), p("c"), C.byref(out)))
+        check(params.fn("dtCFL")(params.device.ctx, r, dx, dy, p("u"), p("v"), p("c"), C.byref(out)))
     return out.value
 
 
 def conservation_vars(params, grid):
     """ref src/reductions.jl:262-323 → (total_mass, total_energy), summed over ranks when use_MPI"""
     r = _range(params, params.steps_ranges[Axis.X].real_domain)
-    ds = (params.domain_size[0] / params.global_grid[0]) * (params.domain_size[1] / params.global_grid[1])
-    out = (C.c_double * 2)()
-    check(_L().armon_hip_conservation_vars(params.device.ctx, r, ds, grid.ptr("rho"), grid.ptr("E"), C.byref(out)))
+    ds = params.cell_size(0) * params.cell_size(1)
+    out = ((C.c_float if params.data_type == np.float32 else C.c_double) * 2)()
+    check(params.fn("conservation_vars")(params.device.ctx, r, ds, grid.ptr("rho"), grid.ptr("E"), C.byref(out)))
     mass, energy = out[0], out[1]
     if params.use_MPI:
         from .halo_exchange import allreduce_sum
@@ -348,14 +354,14 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=
     d.c_out = grid.data["c"].ptr if emit_c else None
     if emit_dt:
         d.dt_cfl_out = grid.dt_scalar.ptr
-        d.cfl_dx = params.domain_size[0] / params.global_grid[0]
-        d.cfl_dy = params.domain_size[1] / params.global_grid[1]
+        d.cfl_dx = params.cell_size(0)
+        d.cfl_dy = params.cell_size(1)
         d.dt_accumulate = int(dt_accumulate)
         grid.dt_pending = True
     if out_range is not None:
         d.out_lo, d.out_hi = out_range
     with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
-        check(_L().armon_hip_sweep(params.device.ctx, C.byref(d)))
+        check(params.fn("sweep")(params.device.ctx, C.byref(d)))
     if swap:
         grid.swap_state()
 
@@ -428,8 +434,8 @@ def solver_cycle(params, grid, last_cycle=True):
     for k, (axis, dt_factor) in enumerate(sweeps):
         # update_solver_state!: ref src/solver_state.jl:339-345
         i_ax = int(axis) - 1
-        dx = params.domain_size[i_ax] / params.global_grid[i_ax]
-        dt = gdt.current_dt * dt_factor
+        dx = params.cell_size(i_ax)
+        dt = gdt.current_dt * params.T(dt_factor)
         if params.use_fused_sweep:
             # The last sweep of a cycle also reduces the next cycle's CFL step (post-sweep u, v with its
             # own pre-sweep c: what the reference's dtCFL_kernel reads) and, on the final
@@ -463,13 +469,14 @@ def time_loop(params, grid):
     gdt = grid.global_dt
     params.wait()
     t1 = _time.perf_counter_ns()
-    while gdt.time < params.maxtime and gdt.cycle < params.maxcycle:
+    maxtime = params.T(params.maxtime)
+    while gdt.time < maxtime and gdt.cycle < params.maxcycle:
         if params.cst_dt:
-            ends = gdt.time + gdt.current_dt >= params.maxtime or gdt.cycle + 1 >= params.maxcycle
+            ends = params.T(gdt.time + gdt.current_dt) >= maxtime or gdt.cycle + 1 >= params.maxcycle
         else:
             # the cycle's dt is only known after next_time_step on cycle 0: be conservative there
             ends = (gdt.cycle + 1 >= params.maxcycle or gdt.current_dt == 0
-                    or gdt.time + gdt.current_dt >= params.maxtime)
+                    or params.T(gdt.time + gdt.current_dt) >= maxtime)
         if solver_cycle(params, grid, last_cycle=ends):
             break
         gdt.next_cycle()
@@ -493,7 +500,7 @@ def time_loop(params, grid):
         print(f"Cells/sec:   {1 / grind_time * 1e3:.5f} Mega cells/sec")
         print(f"Cycles:      {gdt.cycle}")
         print(f"Last cycle:  {gdt.time:.18f} sec, Δt={gdt.current_dt:.18f} sec")
-    return gdt.time, gdt.current_dt, gdt.cycle, 1 / grind_time, solve_time
+    return float(gdt.time), float(gdt.current_dt), gdt.cycle, 1 / grind_time, solve_time
 
 
 def armon(params):

@@ -59,9 +59,10 @@ def _known(name):
     return _CASES[name]
 
 
-def create_test(name, dX):
-    """ref src/tests.jl:13-19 — Sedov's radius depends on the cell size."""
+def create_test(name, dX, T=float):
+    """ref src/tests.jl:13-19 — Sedov's radius depends on the cell size: r::T = hypot(Δx...) / sqrt(2)."""
+    import numpy as np
     kw = dict(_known(name))
     if name == "Sedov":
-        kw["r"] = math.hypot(dX[0], dX[1]) / math.sqrt(2)
+        kw["r"] = float(T(np.hypot(T(dX[0]), T(dX[1])) / math.sqrt(2)))
     return TestCase(name=name, **kw)

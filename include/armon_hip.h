@@ -192,6 +192,46 @@ ARMON_API int armon_hip_init_test(armon_ctx*, armon_range, int test, int64_t row
         int nghost, const int64_t global_pos[2], const int64_t global_N[2],
         const double origin[2], const double dX[2], double sedov_r, const armon_block_data* data);
 
+/* ---- fp32 variants (ref data_type=Float32, src/parameters.jl:185): same kernels, float arrays and scalars ---- */
+typedef struct {
+    float *x, *y, *rho, *u, *v, *E, *p, *c, *g, *us, *ps, *work_1, *work_2, *work_3, *work_4, *mask;
+} armon_block_data_f32;
+
+ARMON_API int armon_hip_perfect_gas_EOS_f32(armon_ctx*, armon_range, float gamma,
+        const float* rho, const float* E, const float* u, const float* v, float* p, float* c, float* g);
+ARMON_API int armon_hip_bizarrium_EOS_f32(armon_ctx*, armon_range,
+        const float* rho, const float* u, const float* v, const float* E, float* p, float* c, float* g);
+ARMON_API int armon_hip_acoustic_f32(armon_ctx*, armon_range, int64_t s, float* us, float* ps,
+        const float* rho, const float* ua, const float* p, const float* c);
+ARMON_API int armon_hip_acoustic_GAD_f32(armon_ctx*, armon_range, int64_t s, float dt, float dx, float* us, float* ps,
+        const float* rho, const float* ua, const float* p, const float* c, int limiter);
+ARMON_API int armon_hip_cell_update_f32(armon_ctx*, armon_range, int64_t s, float dx, float dt,
+        const float* us, const float* ps, float* rho, float* ua, float* E);
+ARMON_API int armon_hip_advection_first_order_f32(armon_ctx*, armon_range, int64_t s, float dt,
+        const float* us, const float* rho, const float* u, const float* v, const float* E,
+        float* adv_rho, float* adv_urho, float* adv_vrho, float* adv_Erho);
+ARMON_API int armon_hip_advection_second_order_f32(armon_ctx*, armon_range, int64_t s, float dx, float dt,
+        const float* us, const float* rho, const float* u, const float* v, const float* E,
+        float* adv_rho, float* adv_urho, float* adv_vrho, float* adv_Erho);
+ARMON_API int armon_hip_euler_projection_f32(armon_ctx*, armon_range, int64_t s, float dx, float dt,
+        const float* us, float* rho, float* u, float* v, float* E,
+        const float* adv_rho, const float* adv_urho, const float* adv_vrho, const float* adv_Erho);
+ARMON_API int armon_hip_boundary_conditions_f32(armon_ctx*, armon_range, int64_t incr, int nghost,
+        float u_factor, float v_factor, float* rho, float* u, float* v, float* p, float* c, float* g, float* E);
+ARMON_API int armon_hip_pack_to_array_f32(armon_ctx*, armon_range, int nghost, int64_t face,
+        float* array, int nvars, const float* const* vars);
+ARMON_API int armon_hip_unpack_from_array_f32(armon_ctx*, armon_range, int nghost, int64_t face,
+        const float* array, int nvars, float* const* vars);
+ARMON_API int armon_hip_dtCFL_async_f32(armon_ctx*, armon_range, float dx, float dy,
+        const float* u, const float* v, const float* c, float* result_dev);
+ARMON_API int armon_hip_dtCFL_f32(armon_ctx*, armon_range, float dx, float dy,
+        const float* u, const float* v, const float* c, float* result_host);
+ARMON_API int armon_hip_conservation_vars_f32(armon_ctx*, armon_range, float ds,
+        const float* rho, const float* E, float out_host[2]);
+ARMON_API int armon_hip_init_test_f32(armon_ctx*, armon_range, int test, int64_t row_length, int64_t col_length,
+        int nghost, const int64_t global_pos[2], const int64_t global_N[2],
+        const float origin[2], const float dX[2], float sedov_r, const armon_block_data_f32* data);
+
 /* ---- fused sweep: EOS → BC (in-tile mirror) → fluxes → cell update → advection → projection ---- */
 /* One call = one directional sweep of solver_cycle (ref src/solver.jl:300-316) over one block, reading
  * (ρ,u,v,E) from `in` and writing them to `out` (ping-pong; `in` and `out` must not alias).
@@ -236,6 +276,46 @@ typedef struct {
 } armon_sweep_desc;
 
 ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
+
+typedef struct {
+    int32_t axis;            /* ARMON_AXIS_X / _Y                                               */
+    int32_t scheme;          /* ARMON_SCHEME_*                                                  */
+    int32_t limiter;         /* ARMON_LIMITER_*  (GAD only)                                     */
+    int32_t projection;      /* ARMON_PROJECTION_*                                              */
+    int32_t eos;             /* ARMON_EOS_*                                                     */
+    int32_t nghost;          /* ghost layers of the arrays (>= scheme·projection stencil)       */
+    int32_t bc_low, bc_high; /* 1: physical boundary on the low/high side of `axis` → mirror BC
+                                applied in-tile; 0: ghosts already hold neighbour data (halo)   */
+    int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to staged  */
+    int32_t x_kernel;        /* X-sweep kernel form, for tests/tuning: 0 default (lanes along x, DPP
+                                shifts, 2 cells per lane), 3 same with 1 cell per lane, 2 LDS-transposed
+                                march                                                            */
+    int64_t nx, ny;          /* real cells of the block                                         */
+    double  dt, dx;          /* sweep time step (current_dt·factor) and cell size along axis    */
+    double  gamma;           /* perfect gas only                                                */
+    double  u_factor_low, v_factor_low, u_factor_high, v_factor_high;   /* BC factors per side  */
+    const float *rho_in, *u_in, *v_in, *E_in;
+    float *rho_out, *u_out, *v_out, *E_out;
+    float *p_out;            /* nullable: EOS pressure of the PRE-sweep state (real cells)      */
+    float *c_out;            /* nullable: EOS sound speed of the PRE-sweep state (real cells)   */
+    /* Fused dt/CFL reduction of the NEXT cycle (ref src/reductions.jl:2-53, src/solver.jl:298): when
+     * dt_cfl_out is non-NULL the sweep also reduces min(cfl_dx/max|u±c|, cfl_dy/max|v±c|) over the real
+     * cells, with the post-sweep u, v and the pre-sweep c — exactly what dtCFL_kernel reads at the start
+     * of the next cycle when this is the last sweep of a cycle — into *dt_cfl_out (one
+     * device double, written by a follow-up fold kernel on the same stream). */
+    float *dt_cfl_out; 
+    double  cfl_dx, cfl_dy;  /* GLOBAL cell sizes along x and y (ref src/reductions.jl:92)        */
+    /* Partial sweeps, for overlapping the halo exchange with compute: produce only the cells
+     * out_lo <= i < out_hi along the sweep axis (0-based real coordinates; out_hi == 0 means the whole
+     * block). The interior [LAG, n-LAG) needs no ghost cell and can run while the halos travel; the two
+     * LAG-wide boundary strips follow once the ghosts are in. dt_accumulate != 0: *dt_cfl_out =
+     * min(*dt_cfl_out, this launch's value) instead of overwriting it. */
+    int64_t out_lo, out_hi;
+    int32_t dt_accumulate;
+    int32_t reserved;
+} armon_sweep_desc_f32;   /* same layout; scalars stay double and are rounded to float inside */
+
+ARMON_API int armon_hip_sweep_f32(armon_ctx*, const armon_sweep_desc_f32*);
 
 #ifdef __cplusplus
 }

@@ -126,7 +126,7 @@ def test_parameters_defaults_follow_the_test_case():
         assert p.nghost == 4 and p.riemann_scheme == "GAD" and p.projection_scheme == "euler_2nd"
         assert p.block_size.size == (58, 48) and p.N_origin == (1, 1) and p.global_grid == (50, 40)
     p = ArmonParameters(test="Sedov", N=(100, 100))
-    assert p.test.r == math.hypot(0.02, 0.02) / math.sqrt(2)            # ref src/tests.jl:15-19
+    assert p.test.r == float(np.hypot(0.02, 0.02) / math.sqrt(2))          # ref src/tests.jl:15-19
     assert p.test.boundary_condition(Side.Left) == (1., 1.)
     assert ArmonParameters(test="Sod").test.boundary_condition(Side.Left) == (-1., 1.)
     assert ArmonParameters(test="Sod_y").test.boundary_condition(Side.Top) == (1., -1.)
@@ -144,7 +144,7 @@ def test_parameters_defaults_follow_the_test_case():
     (dict(cst_dt=True, Dt=0.), "config"),
     (dict(P=(1, 1, 1)), "config"),
     (dict(use_gpu=False), "config"),
-    (dict(data_type=np.float32), "config"),
+    (dict(data_type=np.float16), "config"),
 ])
 def test_parameters_reject_invalid_configurations(kw, category):
     with pytest.raises(armon_amd.SolverException) as e:
