@@ -579,7 +579,9 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     ARMON_REQUIRE(d->scheme != ARMON_SCHEME_GAD || (d->limiter >= ARMON_LIMITER_NONE && d->limiter <= ARMON_LIMITER_SUPERBEE),
                   "unknown limiter tag %d", d->limiter);
     ARMON_REQUIRE(d->nx > 0 && d->ny > 0, "empty block %lld x %lld", (long long)d->nx, (long long)d->ny);
-    ARMON_REQUIRE(d->nx < (1ll << 28) && d->ny < (1ll << 30), "block too large for 32-bit row offsets");
+    // the Y march addresses a run of rows with 32-bit byte offsets from the run's first row
+    ARMON_REQUIRE(d->ny < (1ll << 30) && (d->nx + 2 * (int64_t)d->nghost) * (int64_t)sizeof(real) * (128 + 16) < (1ll << 32),
+                  "block too wide for 32-bit row offsets (%lld cells per row)", (long long)d->nx);
     const int lag = (d->scheme == ARMON_SCHEME_GAD ? 1 : 0) + (d->projection == ARMON_PROJECTION_EULER_2ND ? 1 : 0) + 2;
     ARMON_REQUIRE(d->nghost >= lag, "nghost = %d but this scheme/projection reads %d cells past the block", d->nghost, lag);
     const int64_t n_axis = d->axis == ARMON_AXIS_X ? d->nx : d->ny;

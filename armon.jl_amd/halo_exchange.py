@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check
-from .blocking import Side, axis_of, sides_along
+from .blocking import Side
 from .parameters import PROC_NULL
 
 
@@ -158,11 +158,6 @@ def setup(params, grid):
 def exchange_sides(params, grid, axis, sides, names):
     """Staged path: the reference's comm_vars (ρ,u,v,E,p,c,g) into the ghosts of the remote sides."""
     grid.comm.exchange(sides, names)
-
-
-def exchange_state_halo(params, grid, axis):
-    """Fused path: only (ρ,u,v,E) travel; the sweep recomputes the EOS on the ghosts it reads."""
-    grid.comm.exchange(sides_along(axis), ("rho", "u", "v", "E"))
 
 
 def _allreduce(params, values, op):

@@ -9,7 +9,7 @@ through the C ABI of libarmon_hip.so; nothing here computes on the host.
 import ctypes as C
 import math
 import time as _time
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -157,10 +157,6 @@ class BlockGrid:
 
 
 # ---- per-block kernel wrappers -----------------------------------------------------------------
-
-def _L():
-    return _lib.lib()
-
 
 class _KernelSection:
     """Kernel profiling callbacks — ref ``kernel_start``/``kernel_end`` wrapped around every kernel launch

@@ -294,3 +294,20 @@ def test_write_output_in_reference_format(tmp_path):
     host = aio.read_sub_domain_file(params, "sod")
     for k in ("x", "y", "rho", "u", "v", "p"):
         assert isapprox_count(stats.data.real_view(host[k]), g[k]) == 0, k
+
+
+@pytest.mark.parametrize("fused", MODES)
+@pytest.mark.parametrize("N", [(4, 4), (5, 130), (130, 5), (1, 9), (300, 2), (63, 65), (129, 7)])
+def test_tiny_and_skinny_grids(oracle, N, fused):
+    """Blocks narrower than a wave / shorter than a run, down to the smallest grid the mirror BC allows."""
+    opts = dict(maxcycle=6)
+    if min(N) < 4:
+        opts.update(scheme="Godunov", projection="euler", nghost=2)     # LAG = 2 <= cells along each axis
+        if min(N) < 2:
+            opts.update(axis_splitting="Y_only" if N[0] < 2 else "X_only")
+    params, stats, host = run("Sod_circ", N=N, use_fused_sweep=fused, **opts)
+    orun, f = oracle.solve(test="Sod_circ", N=N, **opts)
+    assert stats.cycles == orun.cycles and stats.last_dt == orun.last_dt
+    g = opts.get("nghost", 4)
+    for k in ("rho", "u", "v", "E", "p"):
+        assert np.array_equal(stats.data.real_view(host[k]), oracle.real_view(f[k], N[0], N[1], g)), k
