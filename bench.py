@@ -59,7 +59,7 @@ def pmc_traffic(args, world):
     """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc passes
     (profiles/r01_pmc_traffic_*.json, made by tools/pmc_to_traffic.py) — only for the exact workload
     they were collected on; otherwise null."""
-    if world != 1 or args.staged or args.exact or args.n != 16384 or args.test != "Sod" or args.scheme != "GAD":
+    if world != 1 or args.staged or args.exact or args.f32 or args.n != 16384 or args.test != "Sod" or args.scheme != "GAD":
         return None
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fused_fast_sod16384.json")
     try:
@@ -112,6 +112,7 @@ def main():
                     help="IEEE division/sqrt, no contraction (bit-identical to the CPU oracle) instead of the "
                          "default tuned arithmetic (shared 1-ulp reciprocals + FMA, within the reference's tolerance)")
     ap.add_argument("--fast", action="store_true", help="(default) tuned arithmetic; kept for compatibility")
+    ap.add_argument("--f32", action="store_true", help="Float32 data_type (the _f32 entry points) instead of the fp64 headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -147,7 +148,7 @@ def main():
         test=args.test, N=N_global, scheme=args.scheme, riemann_limiter="minmod", projection="euler_2nd",
         axis_splitting="Sequential", nghost=4, maxtime=1e9, maxcycle=10 ** 9, silent=5,
         use_MPI=dist is not None, P=P, device_id=local_rank,
-        use_fused_sweep=not args.staged, exact_arithmetic=args.exact)
+        use_fused_sweep=not args.staged, exact_arithmetic=args.exact, data_type="float32" if args.f32 else "float64")
     grid = BlockGrid(params)
     if dist is not None:
         from armon_amd.halo_exchange import setup
@@ -194,7 +195,7 @@ def main():
     durs = timer.durations_ms()
     all_ms = [d for v in durs.values() for d in v]
     mean_ms = sum(all_ms) / max(len(all_ms), 1)
-    bpc = B_PER_CELL[dominant[0]]
+    bpc = B_PER_CELL[dominant[0]] // (2 if args.f32 else 1)
     achieved = bpc * cells_local / (mean_ms * 1e-3) / 1e9 if all_ms else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args, world),
@@ -202,21 +203,22 @@ def main():
                 "mean_launch_ms": round(mean_ms, 4),
                 "per_kernel_ms": {k: round(sum(v) / len(v), 4) for k, v in durs.items()}}
 
+    prec = "fp32" if args.f32 else "fp64"
     out = {
-        "metric": "Mcells/sec per sweep (fp64)", "value": round(value, 1), "unit": "Mcells/s",
+        "metric": f"Mcells/sec per sweep ({prec})", "value": round(value, 1), "unit": "Mcells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.test} {N_global[0]}x{N_global[1]} fp64, {args.scheme}+minmod+euler_2nd, "
+        "vs_baseline": None, "dtype": "f32" if args.f32 else "f64", "data": "synthetic",
+        "config": {"workload": f"{args.test} {N_global[0]}x{N_global[1]} {prec}, {args.scheme}+minmod+euler_2nd, "
                                f"Sequential X,Y splitting, nghost 4, {args.n}x{args.n} cells per GPU",
                    "path": "staged (5 kernels/sweep)" if args.staged else "fused sweep",
                    "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local},
-        "hbm_GBps_algorithmic_whole_job": round(64 * cells_total * sweeps / elapsed / 1e9, 1),
+        "hbm_GBps_algorithmic_whole_job": round((32 if args.f32 else 64) * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.f32:
         try:
             out["cpu_baseline"] = cpu_baseline(args.test, args.scheme)
         except Exception as e:   # the baseline is a reported extra: never lose the GPU line over it
