@@ -45,6 +45,8 @@ struct sweep_args {
     int32_t seg;                   // cells per run along the sweep axis (marching kernels)
     int32_t x_kernel;              // X sweep form: 0 spatial K=2, 3 spatial K=1, 2 LDS-transposed march
     int64_t o_lo, o_hi;            // cells to produce along the sweep axis: [o_lo, o_hi)
+    int64_t x_first;               // X sweep: first cell of strip 0 (<= o_lo, sector-aligned in the ghosted row)
+    int32_t xshift;                // Y sweep: columns the block origin is moved left (line-aligned row segments)
     real dt, dx, gamma;
     real fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const real *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
@@ -167,9 +169,11 @@ k_sweep_y(sweep_args a)
     constexpr int LAG = PIPE::LAG;
     constexpr int PF = ARMON_Y_PF;   // rows in flight per lane, ahead of the march
     const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
-    const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x);
-    const bool active = xr < nx;
-    const int x = active ? xr : nx - 1;          // idle lanes shadow the last column and never store
+    // The block origin is shifted left by a.xshift columns so that a wave's 512-B row segment starts on a
+    // 64-B sector / 128-B line of the ghosted row instead of g cells into one (probe_access: -9 % time).
+    const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x) - a.xshift;
+    const bool active = xr >= 0 && xr < nx;
+    const int x = active ? xr : (xr < 0 ? 0 : nx - 1);   // idle lanes shadow an edge column and never store
     const int o_hi = (int)a.o_hi;
     const int o0 = (int)a.o_lo + (int)blockIdx.y * a.seg;
     const int o1 = (o0 + a.seg < o_hi) ? o0 + a.seg : o_hi;
@@ -229,7 +233,13 @@ k_sweep_y(sweep_args a)
         constexpr bool CHECKED = decltype(checked)::value;
         load(integral_constant<int, PH8 + PF>{}, checked);   // row j + PF → slot (j + PF) mod 8
         real p, c, c_lag;
+#ifdef ARMON_PROBE_NOCOMPUTE   // calibration build: same loads/stores, no arithmetic (tools/build_variant.sh)
+        p = c = c_lag = 0;
+        const auto& cc = pipe.c[PH8 & 7];
+        const fused::Out4<real> out{cc.rho, cc.ua, cc.ut, cc.E};
+#else
         const fused::Out4<real> out = pipe.template advance<true, PH8>(p, c, c_lag);
+#endif
         const int o = j - LAG;
         if (CHECKED) {
             if (a.emit && j >= o0 && j < o1 && active) {
@@ -299,7 +309,9 @@ k_sweep_x_dpp(sweep_args a, int niter)
     SW sw{a.dt, a.dx, a.gamma};
     cfl_track cfl;
 
-    const int64_t w_first = a.o_lo + (int64_t)blockIdx.x * niter * STRIDE;
+    // Strip origins are aligned so that a strip's stores start on a 64-B sector of the ghosted row (for the
+    // usual STRIDE = 120 = 15 sectors); the first strip of a row is then a short one (stores masked below o_lo).
+    const int64_t w_first = a.x_first + (int64_t)blockIdx.x * niter * STRIDE;
     // Strips are real-buffered in registers: the loads of strip it+1 are issued before strip it is
     // computed (the loop is unrolled by the two buffers, so no loaded register is ever copied).
     St buf[2][4];
@@ -348,11 +360,16 @@ k_sweep_x_dpp(sweep_args a, int niter)
         const int64_t j0 = w0 - HALO + (int64_t)lane * K;
 
         St o_rho, o_u, o_v, o_E, p, cs;
+#ifdef ARMON_PROBE_NOCOMPUTE
+        o_rho = buf[B][0]; o_u = buf[B][1]; o_v = buf[B][2]; o_E = buf[B][3]; p = buf[B][0]; cs = buf[B][0];
+#else
         sw.run(buf[B][0], buf[B][1], buf[B][2], buf[B][3], o_rho, o_u, o_v, o_E, p, cs);
+#endif
 
         // cells this lane may store: inside the strip's valid window and inside the block
         const int64_t hi = (w0 + STRIDE < a.o_hi) ? w0 + STRIDE : a.o_hi;
-        if (K == 2 && vec_ok && j0 >= w0 && j0 + 1 < hi) {
+        const int64_t lo = w0 > a.o_lo ? w0 : a.o_lo;
+        if (K == 2 && vec_ok && j0 >= lo && j0 + 1 < hi) {
             *reinterpret_cast<vec2*>(out[0] + j0) = vec2{o_rho.v[0], o_rho.v[K - 1]};
             *reinterpret_cast<vec2*>(out[1] + j0) = vec2{o_u.v[0], o_u.v[K - 1]};
             *reinterpret_cast<vec2*>(out[2] + j0) = vec2{o_v.v[0], o_v.v[K - 1]};
@@ -369,7 +386,7 @@ k_sweep_x_dpp(sweep_args a, int niter)
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const int64_t j = j0 + k;
-                if (j >= w0 && j < hi) {
+                if (j >= lo && j < hi) {
                     out[0][j] = o_rho.v[k];
                     out[1][j] = o_u.v[k];
                     out[2][j] = o_v.v[k];
@@ -498,7 +515,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
 {
     const int64_t n_out = a.o_hi - a.o_lo;
     if (axis == ARMON_AXIS_Y) {
-        dim3 grid((unsigned)((a.nx + kYBlock - 1) / kYBlock), (unsigned)((n_out + a.seg - 1) / a.seg));
+        dim3 grid((unsigned)((a.nx + a.xshift + kYBlock - 1) / kYBlock), (unsigned)((n_out + a.seg - 1) / a.seg));
         *n_blocks = (int64_t)grid.x * grid.y;
         hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
         return check_launch("sweep_y");
@@ -515,7 +532,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     const bool k1 = a.x_kernel == 3;
     const int halo = k1 ? PIPE::LAG : ((PIPE::LAG + 1) & ~1);
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
-    dim3 grid((unsigned)((n_out + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
+    dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
     *n_blocks = (int64_t)grid.x * grid.y;
     if (k1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
@@ -529,9 +546,9 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
 // Upper bound of the number of workgroups any form launches for this block (sizes the partials buffer).
 int64_t max_blocks(const sweep_args& a)
 {
-    const int64_t by = (a.nx + kYBlock - 1) / kYBlock * ((a.ny + a.seg - 1) / a.seg);
+    const int64_t by = (a.nx + 16 + kYBlock - 1) / kYBlock * ((a.ny + a.seg - 1) / a.seg);
     const int64_t bx_lds = (a.nx + a.seg - 1) / a.seg * ((a.ny + kXRows - 1) / kXRows);
-    const int64_t bx_dpp = (a.nx / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows);     // niter >= 1, K = 1, LAG = 4
+    const int64_t bx_dpp = ((a.nx + 8) / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows);     // niter >= 1, K = 1, LAG = 4
     int64_t m = by > bx_lds ? by : bx_lds;
     return m > bx_dpp ? m : bx_dpp;
 }
@@ -633,6 +650,8 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
         a.o_lo = d->out_lo;
         a.o_hi = d->out_hi;
     }
+    a.xshift = X ? 0 : d->nghost % 16;
+    a.x_first = X ? a.o_lo - (a.o_lo + d->nghost) % 8 : 0;
     a.partials = nullptr;
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));
