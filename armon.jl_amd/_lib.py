@@ -78,6 +78,7 @@ SIGNATURES = {
     "armon_hip_free": (_ci, [_vp, _vp]),
     "armon_hip_memcpy": (_ci, [_vp, _vp, _vp, C.c_size_t, _ci]),
     "armon_hip_memset": (_ci, [_vp, _vp, _ci, C.c_size_t]),
+    "armon_hip_stream_copy4": (_ci, [_vp, C.POINTER(_vp * 4), C.POINTER(_vp * 4), C.c_size_t]),
     "armon_hip_timer_start": (_ci, [_vp]),
     "armon_hip_timer_stop": (_ci, [_vp, C.POINTER(_dbl)]),
     "armon_hip_event_record": (_ci, [_vp, _ci]),
@@ -127,22 +128,28 @@ def _add_f32_signatures():
 _add_f32_signatures()
 
 
+def load_at(path):
+    """Load one build of the library and declare every entry point (used for the default build, and by
+    tools/ab_sweep.py to time several builds side by side)."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python armon.jl_amd/build.py` "
+            "(there is no CPU fallback for the device backend)")
+    L = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)   # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if L.armon_hip_flt_size() != 8 or L.armon_hip_idx_size() != 8:   # ref ext/ArmonKokkos.jl:122-139
+        raise RuntimeError("libarmon_hip.so: unexpected flt_size/idx_size")
+    return L
+
+
 def lib():
-    """Load libarmon_hip.so (once) and declare every entry point. Raises if it is not built."""
+    """Load libarmon_hip.so (once). Raises if it is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python armon.jl_amd/build.py` "
-                "(there is no CPU fallback for the device backend)")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)   # AttributeError if the library does not export it
-            fn.restype = res
-            fn.argtypes = args
-        if L.armon_hip_flt_size() != 8 or L.armon_hip_idx_size() != 8:   # ref ext/ArmonKokkos.jl:122-139
-            raise RuntimeError("libarmon_hip.so: unexpected flt_size/idx_size")
-        _lib = L
+        _lib = load_at(LIB_PATH)
     return _lib
 
 

@@ -188,6 +188,37 @@ int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes)
     return ARMON_OK;
 }
 
+namespace {
+struct copy4_args { const double2* in[4]; double2* out[4]; };
+
+__global__ void __launch_bounds__(256) k_stream_copy4(copy4_args p, size_t n2)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n2) return;
+    double2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = p.in[k][i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) p.out[k][i] = v[k];
+}
+}  // namespace
+
+int armon_hip_stream_copy4(armon_ctx* ctx, const void* const in[4], void* const out[4], size_t bytes)
+{
+    ARMON_REQUIRE(ctx && in && out, "NULL argument");
+    ARMON_REQUIRE(bytes % 16 == 0 && bytes / 16 / 256 < (1ull << 31), "bytes = %zu: multiple of 16 expected", bytes);
+    if (bytes == 0) return ARMON_OK;
+    copy4_args p;
+    for (int k = 0; k < 4; k++) {
+        ARMON_REQUIRE(in[k] && out[k], "NULL array");
+        p.in[k] = static_cast<const double2*>(in[k]);
+        p.out[k] = static_cast<double2*>(out[k]);
+    }
+    const size_t n2 = bytes / 16;
+    hipLaunchKernelGGL(k_stream_copy4, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream, p, n2);
+    return check_launch("stream_copy4");
+}
+
 int armon_hip_timer_start(armon_ctx* ctx)
 {
     ARMON_REQUIRE(ctx, "ctx is NULL");

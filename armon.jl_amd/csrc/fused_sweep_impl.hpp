@@ -37,6 +37,27 @@ namespace {
 using real = ARMON_SWEEP_REAL;
 using vec2 = std::conditional<std::is_same<real, double>::value, double2, float2>::type;
 
+// Streaming hints (tuning macros, see tools/build_variant.sh): the state is read once and written once per
+// sweep and is far larger than L2 + MALL, so `nt` keeps it from displacing the halo rows/columns that ARE
+// re-read. Bit 0 of ARMON_NT: loads, bit 1: stores.
+#ifndef ARMON_NT
+#define ARMON_NT 2
+#endif
+typedef real vreal2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vec2 ld2(const real* p)
+{
+    const vreal2* q = reinterpret_cast<const vreal2*>(p);
+    const vreal2 v = (ARMON_NT & 1) ? __builtin_nontemporal_load(q) : *q;
+    return vec2{v.x, v.y};
+}
+__device__ __forceinline__ void st2(real* p, real x, real y)
+{
+    vreal2* q = reinterpret_cast<vreal2*>(p);
+    const vreal2 v = {x, y};
+    if (ARMON_NT & 2) __builtin_nontemporal_store(v, q);
+    else *q = v;
+}
+
 struct sweep_args {
     int64_t nx, ny, row_len;       // real cells and array pitch (nx + 2g)
     int32_t g;                     // ghost layers
@@ -90,25 +111,26 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
 }
+constexpr int kAuxLoad = (ARMON_NT & 1) ? 2 : 0, kAuxStore = (ARMON_NT & 2) ? 2 : 0;   // gfx950 cache policy: bit 1 = nt
 template <typename T> __device__ __forceinline__ T buf_load(rsrc_t r, unsigned voff, unsigned soff);
 template <>
 __device__ __forceinline__ double buf_load<double>(rsrc_t r, unsigned voff, unsigned soff)
 {
-    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxLoad);
     return __builtin_bit_cast(double, v);
 }
 template <>
 __device__ __forceinline__ float buf_load<float>(rsrc_t r, unsigned voff, unsigned soff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxLoad));
 }
 __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff, double x)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, soff, kAuxStore);
 }
 __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff, float x)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), r, voff, soff, kAuxStore);
 }
 
 // dt/CFL tracking (ref src/reductions.jl:13-20). The reference takes min over cells of
@@ -284,7 +306,7 @@ k_sweep_y(sweep_args a)
 // blockDim = (64, kXSRows): one wave per row, kXSRows consecutive rows per workgroup. Each wave walks
 // NITER strips of 64*K cells along its row; a strip yields 64*K - 2*HALO new cells.
 constexpr int kXSRows = 4;
-constexpr int kXSNiter = 8;      // strips per wave
+constexpr int kXSNiter = 2;      // strips per wave (A/B over 1..137 with tools/ab_sweep.py: short-lived waves keep the global access order sequential)
 
 template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
 __global__ void __launch_bounds__(64 * kXSRows)
@@ -326,10 +348,10 @@ k_sweep_x_dpp(sweep_args a, int niter)
         const bool interior = cb >= 0 && cb + WIDTH <= a.nx;          // uniform: no ghost, no clamping
         if (interior && (K == 1 || vec_ok)) {
             if (K == 2) {
-                const vec2 r = *reinterpret_cast<const vec2*>(in[0] + j0);
-                const vec2 u = *reinterpret_cast<const vec2*>(in[1] + j0);
-                const vec2 v = *reinterpret_cast<const vec2*>(in[2] + j0);
-                const vec2 e = *reinterpret_cast<const vec2*>(in[3] + j0);
+                const vec2 r = ld2(in[0] + j0);
+                const vec2 u = ld2(in[1] + j0);
+                const vec2 v = ld2(in[2] + j0);
+                const vec2 e = ld2(in[3] + j0);
                 rho.v[0] = r.x; rho.v[K - 1] = r.y;
                 ua.v[0] = u.x; ua.v[K - 1] = u.y;
                 ut.v[0] = v.x; ut.v[K - 1] = v.y;
@@ -370,13 +392,13 @@ k_sweep_x_dpp(sweep_args a, int niter)
         const int64_t hi = (w0 + STRIDE < a.o_hi) ? w0 + STRIDE : a.o_hi;
         const int64_t lo = w0 > a.o_lo ? w0 : a.o_lo;
         if (K == 2 && vec_ok && j0 >= lo && j0 + 1 < hi) {
-            *reinterpret_cast<vec2*>(out[0] + j0) = vec2{o_rho.v[0], o_rho.v[K - 1]};
-            *reinterpret_cast<vec2*>(out[1] + j0) = vec2{o_u.v[0], o_u.v[K - 1]};
-            *reinterpret_cast<vec2*>(out[2] + j0) = vec2{o_v.v[0], o_v.v[K - 1]};
-            *reinterpret_cast<vec2*>(out[3] + j0) = vec2{o_E.v[0], o_E.v[K - 1]};
+            st2(out[0] + j0, o_rho.v[0], o_rho.v[K - 1]);
+            st2(out[1] + j0, o_u.v[0], o_u.v[K - 1]);
+            st2(out[2] + j0, o_v.v[0], o_v.v[K - 1]);
+            st2(out[3] + j0, o_E.v[0], o_E.v[K - 1]);
             if (a.emit) {
-                if (a.emit & 1) *reinterpret_cast<vec2*>(a.p_out + row_off + j0) = vec2{p.v[0], p.v[K - 1]};
-                if (a.emit & 2) *reinterpret_cast<vec2*>(a.c_out + row_off + j0) = vec2{cs.v[0], cs.v[K - 1]};
+                if (a.emit & 1) st2(a.p_out + row_off + j0, p.v[0], p.v[K - 1]);
+                if (a.emit & 2) st2(a.c_out + row_off + j0, cs.v[0], cs.v[K - 1]);
             }
             if (TRACK) {
                 cfl.add(o_u.v[0], o_v.v[0], cs.v[0]);
@@ -527,7 +549,8 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         hipLaunchKernelGGL((k_sweep_x_lds<PIPE, kXChunk, TRACK>), grid, dim3(kXRows), lds, ctx->stream, a);
         return check_launch("sweep_x_lds");
     }
-    static const int niter_env = getenv("ARMON_XS_NITER") ? atoi(getenv("ARMON_XS_NITER")) : 0;   // tuning knob
+    const char* niter_s = getenv("ARMON_XS_NITER");                  // tuning knob, read per launch (A/B runs)
+    const int niter_env = niter_s ? atoi(niter_s) : 0;
     const int niter = niter_env > 0 ? niter_env : kXSNiter;
     const bool k1 = a.x_kernel == 3;
     const int halo = k1 ? PIPE::LAG : ((PIPE::LAG + 1) & ~1);
@@ -639,7 +662,8 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.E_out = d->E_out;
     a.p_out = d->p_out;
     a.c_out = d->c_out;
-    static const int seg_y_env = getenv("ARMON_Y_SEG") ? atoi(getenv("ARMON_Y_SEG")) : 0;        // tuning knob
+    const char* seg_s = getenv("ARMON_Y_SEG");                       // tuning knob, read per launch (A/B runs)
+    const int seg_y_env = seg_s ? atoi(seg_s) : 0;
     a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : 128);
     a.x_kernel = d->x_kernel;
     a.o_lo = 0;
@@ -650,8 +674,10 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
         a.o_lo = d->out_lo;
         a.o_hi = d->out_hi;
     }
-    a.xshift = X ? 0 : d->nghost % 16;
-    a.x_first = X ? a.o_lo - (a.o_lo + d->nghost) % 8 : 0;
+    const char* align_s = getenv("ARMON_SWEEP_ALIGN");               // tuning knob: "0" = unaligned origins (A/B runs)
+    const bool align = !(align_s && align_s[0] == '0');
+    a.xshift = (X || !align) ? 0 : d->nghost % 16;
+    a.x_first = X ? (align ? a.o_lo - (a.o_lo + d->nghost) % 8 : a.o_lo) : 0;
     a.partials = nullptr;
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));

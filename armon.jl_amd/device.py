@@ -61,6 +61,12 @@ class HIPDevice:
         check(self._L.armon_hip_timer_stop(self.ctx, C.byref(ms)))
         return ms.value
 
+    def stream_copy4(self, src, dst, nbytes):
+        """Measurement aid: copy 4 device arrays into 4 others in one launch (the sweep's traffic shape)."""
+        a = (C.c_void_p * 4)(*[x.ptr for x in src])
+        b = (C.c_void_p * 4)(*[x.ptr for x in dst])
+        check(self._L.armon_hip_stream_copy4(self.ctx, C.byref(a), C.byref(b), int(nbytes)))
+
     def event_record(self, slot):
         check(self._L.armon_hip_event_record(self.ctx, int(slot)))
 

@@ -328,6 +328,18 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=
     """One directional sweep as a single kernel launch (armon_hip_sweep). The halo cells of process
     boundaries must already hold the neighbour's (ρ,u,v,E). ``emit_dt``: also reduce the CFL time step
     of the resulting state into ``grid.dt_scalar`` (device)."""
+    d = sweep_desc(params, grid, axis, dt, dx, emit_p, emit_c, emit_dt, out_range, dt_accumulate)
+    if emit_dt:
+        grid.dt_pending = True
+    with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
+        check(params.fn("sweep")(params.device.ctx, C.byref(d)))
+    if swap:
+        grid.swap_state()
+
+
+def sweep_desc(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=False, out_range=None,
+               dt_accumulate=False):
+    """The ``armon_sweep_desc`` of one sweep of ``grid``'s current state into its alternate arrays."""
     d = SweepDesc()
     d.axis = 0 if axis == Axis.X else 1
     d.scheme = SCHEMES[params.riemann_scheme]
@@ -353,13 +365,9 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=
         d.cfl_dx = params.cell_size(0)
         d.cfl_dy = params.cell_size(1)
         d.dt_accumulate = int(dt_accumulate)
-        grid.dt_pending = True
     if out_range is not None:
         d.out_lo, d.out_hi = out_range
-    with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
-        check(params.fn("sweep")(params.device.ctx, C.byref(d)))
-    if swap:
-        grid.swap_state()
+    return d
 
 
 def fused_sweep_overlapped(params, grid, axis, dt, dx, **emit):

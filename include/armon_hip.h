@@ -97,6 +97,12 @@ ARMON_API int armon_hip_free(armon_ctx* ctx, void* ptr);
 ARMON_API int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind); /* async */
 ARMON_API int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes);             /* async */
 
+/* Measurement aid (bench.py): plain streaming copy of four arrays into four others in ONE launch —
+ * the traffic shape of a fused sweep (4 read + 4 written, 16 B per lane) with no arithmetic. Its rate on
+ * the device at hand is the practical ceiling the sweep kernels are compared with, next to the 8 TB/s
+ * spec. `bytes` per array, multiple of 16; async on the context's stream. No reference counterpart. */
+ARMON_API int armon_hip_stream_copy4(armon_ctx* ctx, const void* const in[4], void* const out[4], size_t bytes);
+
 /* stream timers for benchmarks (hipEvents on the context's stream).
  * event_record/event_elapsed: a pool of ARMON_HIP_MAX_EVENTS reusable events, recorded without any
  * host synchronisation; event_elapsed_ms synchronises on event `b` and returns t(b) - t(a). */

@@ -88,6 +88,19 @@ def test_device_array_roundtrip_and_meminfo(dev):
     assert "gfx950" in dev.name
 
 
+def test_stream_copy4(dev):
+    """The measurement aid bench.py uses as the same-device streaming ceiling really copies 4 arrays into 4."""
+    rng = np.random.default_rng(3)
+    src = [rng.random(4098) for _ in range(4)]
+    d_src = [dev.from_host(a) for a in src]
+    d_dst = [dev.zeros(4098) for _ in range(4)]
+    dev.stream_copy4(d_src, d_dst, src[0].nbytes)
+    for a, d in zip(src, d_dst):
+        assert np.array_equal(d.to_host(), a)
+    with pytest.raises(Exception):
+        dev.stream_copy4(d_src, d_dst, 24)          # not a multiple of 16
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_perfect_gas_EOS(dev, L, oracle, shape):
     nx, ny = shape

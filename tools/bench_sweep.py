@@ -23,6 +23,9 @@ ap.add_argument("--projection", default="euler_2nd")
 ap.add_argument("--emit", action="store_true")
 ap.add_argument("--track", action="store_true", help="fused dt/CFL reduction on the Y sweep")
 ap.add_argument("--modes", default="exact,fast")
+ap.add_argument("--niter", default="", help="comma list of ARMON_XS_NITER values to interleave (X sweep)")
+ap.add_argument("--seg", default="", help="comma list of ARMON_Y_SEG values to interleave (Y sweep)")
+ap.add_argument("--align", default="", help="comma list of ARMON_SWEEP_ALIGN values to interleave (0 = unaligned origins)")
 ap.add_argument("--xk", default="0", help="comma list of X kernel forms: 0 spatial K=2, 3 spatial K=1, 1 LDS vec, 2 LDS generic")
 args = ap.parse_args()
 ny = args.ny or args.n
@@ -39,18 +42,27 @@ res = {}
 for r in range(args.rounds + 1):
     for mode in args.modes.split(","):
         params.exact_arithmetic = mode == "exact"
-        for axis, xk in [(Axis.X, int(k)) for k in args.xk.split(",")] + [(Axis.Y, 0)]:
+        als = args.align.split(",") if args.align else [""]
+        cfgs = [(Axis.X, int(k), nit, "", al) for k in args.xk.split(",") for nit in (args.niter.split(",") if args.niter else [""]) for al in als]
+        cfgs += [(Axis.Y, 0, "", sg, al) for sg in (args.seg.split(",") if args.seg else [""]) for al in als]
+        for axis, xk, nit, sg, al in cfgs:
             params.x_kernel = xk
+            for key, val in (("ARMON_XS_NITER", nit), ("ARMON_Y_SEG", sg), ("ARMON_SWEEP_ALIGN", al)):
+                if val:
+                    os.environ[key] = val
+                else:
+                    os.environ.pop(key, None)
             dev.event_record(0)
             fused_sweep(params, grid, axis, dt, dx, emit_p=args.emit, emit_c=args.emit, emit_dt=args.track and axis == Axis.Y)
             dev.event_record(1)
             ms = dev.event_elapsed_ms(0, 1)
             if r > 0:
-                res.setdefault((mode, axis.name + (str(xk) if axis == Axis.X else "")), []).append(ms)
+                tag = axis.name + (str(xk) if axis == Axis.X else "") + (f" niter={nit}" if nit else "") + (f" seg={sg}" if sg else "") + (f" align={al}" if al else "")
+                res.setdefault((mode, tag), []).append(ms)
     # keep the state sane (a few sweeps of Sod are harmless, but do not let it drift for long)
     if r % 3 == 2:
         init_test(params, grid)
 for (mode, axis), v in res.items():
     med = statistics.median(v)
-    print(f"{mode:5s} sweep_{axis}: median {med:7.3f} ms  min {min(v):7.3f} ms   "
+    print(f"{mode:5s} sweep_{axis:22s}: median {med:7.3f} ms  min {min(v):7.3f} ms   "
           f"{64 * cells / med / 1e6:7.1f} GB/s algorithmic   {cells / med / 1e3:8.1f} Mcells/s")

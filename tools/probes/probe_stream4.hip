@@ -11,6 +11,25 @@
 
 struct ptrs { const double2* in[4]; double2* out[4]; };
 
+// NT bit 0: nontemporal loads, bit 1: nontemporal stores
+template <int NT>
+__global__ __launch_bounds__(256) void k_stream_nt(ptrs p, size_t n2)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    double2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (NT & 1) { v[k].x = __builtin_nontemporal_load(&p.in[k][i].x); v[k].y = __builtin_nontemporal_load(&p.in[k][i].y); }
+        else v[k] = p.in[k][i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (NT & 2) { __builtin_nontemporal_store(v[k].x, &p.out[k][i].x); __builtin_nontemporal_store(v[k].y, &p.out[k][i].y); }
+        else p.out[k][i] = v[k];
+    }
+}
+
 template <int NF>
 __global__ __launch_bounds__(256) void k_stream(ptrs p, size_t n2, double a, double b)
 {
@@ -66,6 +85,27 @@ int main()
         p.in[k] = (const double2*)a; p.out[k] = (double2*)b;
     }
     CK(hipDeviceSynchronize());
+    {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int blocks = (int)((n2 + 255) / 256);
+        for (int rep = 0; rep < 2; rep++)
+        for (int nt = 0; nt < 4; nt++) {
+            std::vector<float> ms;
+            for (int it = 0; it < 9; it++) {
+                CK(hipEventRecord(e0));
+                if (nt == 0) k_stream_nt<0><<<blocks, 256>>>(p, n2);
+                if (nt == 1) k_stream_nt<1><<<blocks, 256>>>(p, n2);
+                if (nt == 2) k_stream_nt<2><<<blocks, 256>>>(p, n2);
+                if (nt == 3) k_stream_nt<3><<<blocks, 256>>>(p, n2);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                if (it >= 2) ms.push_back(t);
+            }
+            std::sort(ms.begin(), ms.end());
+            printf("full-grid copy, nt loads %d nt stores %d: median %.3f ms  %.2f TB/s\n", nt & 1, (nt >> 1) & 1, ms[ms.size() / 2],
+                   8.0 * n2 * 16 / ms[ms.size() / 2] / 1e9);
+        }
+    }
     int blocks_list[] = {256 * 8, 256 * 16, 256 * 64, (int)((n2 + 255) / 256)};
     for (int b : blocks_list) if (run<0>(p, n2, b, "copy 4in/4out")) return 1;
     if (run<8>(p, n2, 256 * 16, "copy + fma")) return 1;
