@@ -103,10 +103,24 @@ class DeviceArray:
         check(device._L.armon_hip_malloc(device.ctx, self.nbytes, C.byref(p)))
         self.ptr = p.value or 0
 
+    @classmethod
+    def view(cls, owner, byte_offset, n, dtype):
+        """A sub-array of ``owner``'s allocation (no ownership: it keeps ``owner`` alive instead)."""
+        a = cls.__new__(cls)
+        a.device, a.n, a.dtype = owner.device, int(n), np.dtype(dtype)
+        a.nbytes = a.n * a.dtype.itemsize
+        assert byte_offset % 256 == 0 and byte_offset + a.nbytes <= owner.nbytes
+        a.ptr = owner.ptr + byte_offset
+        a.owner = owner
+        return a
+
     def __len__(self):
         return self.n
 
     def free(self):
+        if getattr(self, "owner", None) is not None:
+            self.ptr, self.owner = 0, None
+            return
         if self.ptr and self.device.ctx:
             self.device._L.armon_hip_free(self.device.ctx, C.c_void_p(self.ptr))
         self.ptr = 0

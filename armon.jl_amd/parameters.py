@@ -206,12 +206,14 @@ class ArmonParameters:
 
     # ref src/parameters.jl:766-778 — backend specific options (like ext/ArmonKokkos.jl:83-87)
     def _init_backend(self, device_id=None, use_fused_sweep=True, exact_arithmetic=False, stream=None,
-                      **options):
+                      placement_tries=8, **options):
         """``device_id``: GPU ordinal (default LOCAL_RANK or 0). ``use_fused_sweep``: run each sweep as
         the fused HIP kernel instead of the 5 staged kernels. ``exact_arithmetic=True``: IEEE division/sqrt
         and no FMA contraction in the fused sweep (bit-identical to the staged path and to the CPU oracle);
         the default tuned arithmetic (shared 1-ulp reciprocals, FMAs) stays within the reference's own
-        golden-file tolerance (atol 1e-13, rtol 4 eps on the Sod family)."""
+        golden-file tolerance (atol 1e-13, rtol 4 eps on the Sod family). ``placement_tries``: how many
+        placements of the state vectors in HBM ``init_test`` may try (0/1 = take the first; see
+        ``BlockGrid.tune_placement``)."""
         import os
         if device_id is None:
             device_id = int(os.environ.get("LOCAL_RANK", "0")) if self.use_MPI else 0
@@ -221,6 +223,7 @@ class ArmonParameters:
         # per-step dumps / comparisons need the intermediate states: only the staged path has them
         self.use_fused_sweep = bool(use_fused_sweep) and not self.compare
         self.exact_arithmetic = bool(exact_arithmetic)
+        self.placement_tries = int(placement_tries)
         self.backend_options = dict(device_id=device_id, use_fused_sweep=self.use_fused_sweep,
                                     exact_arithmetic=self.exact_arithmetic)
         return options

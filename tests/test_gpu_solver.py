@@ -311,3 +311,28 @@ def test_tiny_and_skinny_grids(oracle, N, fused):
     g = opts.get("nghost", 4)
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(stats.data.real_view(host[k]), oracle.real_view(f[k], N[0], N[1], g)), k
+
+
+def test_tune_placement_keeps_the_state(oracle):
+    """BlockGrid.tune_placement re-allocates the state vectors (measured choice of the HBM placement): the state
+    and the results must not change, whichever draw wins."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, init_test
+    params = armon_amd.ArmonParameters(test="Sod_circ", N=(96, 64), silent=5, maxcycle=6, placement_tries=4)
+    grid = BlockGrid(params)
+    init_test(params, grid)                    # small block: tuning skipped by size
+    assert grid.placement is None
+    before = grid.device_to_host(("rho", "u", "v", "E"))
+    ptrs = {f: grid.data[f].ptr for f in before}
+    rep = grid.tune_placement(min_bytes=0)
+    assert rep and 2 <= rep["tries"] <= 4 and len(rep["x_plus_y_ms"]) == rep["tries"]
+    after = grid.device_to_host(("rho", "u", "v", "E"))
+    for f in before:
+        assert np.array_equal(before[f], after[f])
+    if rep["chosen"] != 0:
+        assert all(grid.data[f].ptr != ptrs[f] for f in before)
+    # and a whole run with tuning forced on every block size gives the same result as one without
+    ref, ref_fields = oracle.solve(test="Sod_circ", N=(96, 64), maxcycle=6)
+    _p, stats, host = run("Sod_circ", N=(96, 64), maxcycle=6, placement_tries=1)
+    assert stats.cycles == ref.cycles
+    assert np.array_equal(oracle.real_view(host["rho"], 96, 64, G), oracle.real_view(ref_fields["rho"], 96, 64, G))

@@ -22,13 +22,17 @@ ap.add_argument("--n", type=int, default=16384)
 ap.add_argument("--rounds", type=int, default=20)
 ap.add_argument("--test", default="Sod")
 ap.add_argument("--exact", action="store_true")
+ap.add_argument("--scheme", default="GAD")
+ap.add_argument("--projection", default="euler_2nd")
+ap.add_argument("--f32", action="store_true")
 ap.add_argument("--env", default="", help="per-build env: name:KEY=VAL,KEY=VAL;name2:... applied around that build's launches")
 ap.add_argument("--gap-ms", type=float, default=0., help="idle time before every launch (clock/power recovery experiments)")
 ap.add_argument("--copy", action="store_true", help="also time armon_hip_stream_copy4 on the same arrays (same bytes, no arithmetic)")
 ap.add_argument("libs", nargs="+", help="name=path")
 args = ap.parse_args()
 
-params = armon_amd.ArmonParameters(test=args.test, N=(args.n, args.n), silent=5, maxcycle=10, exact_arithmetic=args.exact)
+params = armon_amd.ArmonParameters(test=args.test, N=(args.n, args.n), silent=5, maxcycle=10, exact_arithmetic=args.exact,
+                                   scheme=args.scheme, projection=args.projection, data_type="float32" if args.f32 else "float64")
 grid = BlockGrid(params)
 init_test(params, grid)
 params.wait()
@@ -62,7 +66,7 @@ for r in range(args.rounds + 2):
             if args.gap_ms:
                 time.sleep(args.gap_ms * 1e-3)
             _lib.check(L.armon_hip_event_record(ctx, 0))
-            _lib.check(L.armon_hip_sweep(ctx, C.byref(d)))
+            _lib.check(getattr(L, "armon_hip_sweep" + params.suffix)(ctx, C.byref(d)))
             _lib.check(L.armon_hip_event_record(ctx, 1))
             ms = C.c_double()
             _lib.check(L.armon_hip_event_elapsed_ms(ctx, 0, 1, C.byref(ms)))
@@ -84,4 +88,4 @@ for (axis, name), v in res.items():
     med = statistics.median(v)
     base.setdefault(axis, med)
     print(f"sweep_{axis} {name:12s}: median {med:7.3f} ms  min {min(v):7.3f}  max {max(v):7.3f}   "
-          f"{64 * args.n * args.n / med / 1e6:7.1f} GB/s   x{med / base[axis]:.3f} vs first")
+          f"{(32 if args.f32 else 64) * args.n * args.n / med / 1e6:7.1f} GB/s   x{med / base[axis]:.3f} vs first")
