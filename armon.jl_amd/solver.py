@@ -140,70 +140,70 @@ class BlockGrid:
         for f in STATE_VARS:
             self.data[f], self.alt[f] = self.alt[f], self.data[f]
 
-    def tune_placement(self, min_bytes=256 << 20):
+    def tune_placement(self, min_bytes=256 << 20, spare=8):
         """Pick a good PHYSICAL placement for the 8 vectors a fused sweep streams (4 read + 4 written).
 
-        On MI355X the same kernels on the same virtual layout run in one of two regimes depending on where
-        hipMalloc happened to put the vectors in HBM (tools/placement_lottery.py: X 2.93-3.00 / Y 2.99-3.08 ms
-        against X 3.23 / Y 3.59 ms on Sod 16384², about half of the draws each; a single slab always lands in
-        between). Nothing visible from user space predicts the regime, so it is measured: time one X and one Y
-        sweep of the current state, allocate another set of vectors (the previous ones are held so that the
-        new set lands elsewhere), copy the state over, time again; after ``placement_tries`` draws keep the
-        fastest set and free the rest (intermediate regimes exist, so there is no early exit). Called by
-        ``init_test``; costs a few tens of ms per try, outside any timed region. Returns the report also stored in ``self.placement``."""
+        On MI355X the same kernels on the same virtual layout run 10-20 % apart depending on where the 8
+        vectors sit in HBM relative to each other: vectors allocated back to back end up at a REGULAR
+        physical spacing, and for many spacings the 8 streams then keep meeting on the same channels/banks
+        (tools/probes/probe_skew.hip, probe_pairs.hip: 2.93-3.77 ms for the same copy as a function of the
+        spacing; random picks of 8 among 24 such vectors: 75 % at 2.71-2.79 ms, the back-to-back groups 2.94-3.08).
+        Nothing visible from user space predicts it, so it is measured: ``spare`` extra vectors are allocated,
+        ``placement_tries`` assignments of the 8 roles to vectors of the pool are timed with one X and one Y
+        sweep of the real state (the first one being the back-to-back assignment), the fastest is kept and
+        the unused vectors are freed. Called by ``init_test``; ~20 ms per try, outside any timed region.
+        Returns the report also stored in ``self.placement``."""
         params, dev = self.params, self.params.device
         tries = getattr(params, "placement_tries", 0)
         nbytes = self.data["rho"].nbytes
         if self.alt is None or tries <= 1 or nbytes < min_bytes:
             return None
+        free, _total = dev.memory_info()
+        spare = int(min(spare, (free * 0.8) // nbytes - 4))      # 4 more vectors park the state meanwhile
+        if spare < 1:
+            return None
         dx = params.cell_size(0)
         dt = 1e-3 * dx                    # any small step: the arithmetic does not depend on the data
+        n, dt_ = self.data["rho"].n, self.data["rho"].dtype
+        pool = [self.data[f] for f in STATE_VARS] + [self.alt[f] for f in STATE_VARS]
+        pool += [dev.empty(n, dt_) for _ in range(spare)]
+        master = {f: dev.empty(n, dt_) for f in STATE_VARS}     # the state is parked here while roles move around
+        for f in STATE_VARS:
+            master[f].copy_from_device(self.data[f])
 
-        def timed(data, alt):
-            saved = {f: (self.data[f], self.alt[f]) for f in STATE_VARS}
-            for f in STATE_VARS:
-                self.data[f], self.alt[f] = data[f], alt[f]
+        def assign(pick):
+            for k, f in enumerate(STATE_VARS):
+                self.data[f], self.alt[f] = pool[pick[k]], pool[pick[4 + k]]
+                self.data[f].copy_from_device(master[f])
+
+        def timed():
             best = math.inf
-            try:
-                for rep in range(3):
-                    dev.event_record(ARMON_EVENT_SCRATCH)
-                    for axis in (Axis.X, Axis.Y):
-                        d = sweep_desc(params, self, axis, dt, dx, emit_dt=axis == Axis.Y)   # as in a cycle
-                        check(params.fn("sweep")(dev.ctx, C.byref(d)))
-                    dev.event_record(ARMON_EVENT_SCRATCH + 1)
-                    ms = dev.event_elapsed_ms(ARMON_EVENT_SCRATCH, ARMON_EVENT_SCRATCH + 1)
-                    if rep:
-                        best = min(best, ms)
-            finally:
-                for f in STATE_VARS:
-                    self.data[f], self.alt[f] = saved[f]
+            for rep in range(3):
+                dev.event_record(ARMON_EVENT_SCRATCH)
+                for axis in (Axis.X, Axis.Y):
+                    d = sweep_desc(params, self, axis, dt, dx, emit_dt=axis == Axis.Y)   # as in a cycle
+                    check(params.fn("sweep")(dev.ctx, C.byref(d)))
+                dev.event_record(ARMON_EVENT_SCRATCH + 1)
+                ms = dev.event_elapsed_ms(ARMON_EVENT_SCRATCH, ARMON_EVENT_SCRATCH + 1)
+                if rep:
+                    best = min(best, ms)
             return best
 
-        cands = [(timed(self.data, self.alt), {f: self.data[f] for f in STATE_VARS}, dict(self.alt))]
-        for _ in range(tries - 1):
-            free, _total = dev.memory_info()
-            if free < 8 * nbytes * 1.25:
-                break
-            data = {f: dev.empty(self.data[f].n, self.data[f].dtype) for f in STATE_VARS}
-            alt = {f: dev.empty(self.data[f].n, self.data[f].dtype) for f in STATE_VARS}
-            for f in STATE_VARS:
-                data[f].copy_from_device(self.data[f])
-            cands.append((timed(data, alt), data, alt))
-        times = [c[0] for c in cands]
+        rng = np.random.default_rng(12345)
+        picks = [list(range(8))] + [[int(i) for i in rng.permutation(len(pool))[:8]] for _ in range(tries - 1)]
+        times = []
+        for pick in picks:
+            assign(pick)
+            times.append(timed())
         k = times.index(min(times))
-        _t, data, alt = cands[k]
-        for f in STATE_VARS:
-            if data[f] is not self.data[f]:
-                data[f].copy_from_device(self.data[f])      # the state may have been touched since (it was not; cheap)
+        assign(picks[k])
         dev.wait()
-        for i, (_t, d_, a_) in enumerate(cands):
-            if i != k:
-                for f in STATE_VARS:
-                    d_[f].free()
-                    a_[f].free()
-        for f in STATE_VARS:
-            self.data[f], self.alt[f] = data[f], alt[f]
-        self.placement = {"tries": len(cands), "x_plus_y_ms": [round(t, 3) for t in times], "chosen": k}
+        keep = {id(pool[i]) for i in picks[k]}
+        for v in pool + list(master.values()):
+            if id(v) not in keep:
+                v.free()
+        self.placement = {"tries": len(picks), "pool": len(pool),
+                          "x_plus_y_ms": [round(t, 3) for t in times], "chosen": k}
         return self.placement
 
     def device_to_host(self, names=MAIN_VARS):
