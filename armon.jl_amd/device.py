@@ -117,6 +117,11 @@ class DeviceArray:
     def __len__(self):
         return self.n
 
+    @property
+    def __cuda_array_interface__(self):
+        """Zero-copy view for torch (``torch.as_tensor(a, device="cuda")``): collectives on device scalars."""
+        return {"shape": (self.n,), "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2}
+
     def free(self):
         if getattr(self, "owner", None) is not None:
             self.ptr, self.owner = 0, None

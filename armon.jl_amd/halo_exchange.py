@@ -40,6 +40,10 @@ class HaloExchanger:
         self.group = params.global_comm
         backend = dist.get_backend(self.group)
         self.device_buffers = backend == "nccl" and host_arrays is None
+        if self.device_buffers:
+            params.device                      # make sure the context exists (it may adopt a torch stream)
+        # RCCL + every kernel on torch's current stream: pack → send and recv → unpack are ordered on the device
+        self.stream_ordered = self.device_buffers and getattr(params, "shared_stream", False)
         bs = params.block_size
         self.buf = {}
         for side in Side:
@@ -94,7 +98,7 @@ class HaloExchanger:
         bs = p.block_size
         for s in sides:
             self.pack(s, names)
-        if self.host_arrays is None:
+        if self.host_arrays is None and not self.stream_ordered:
             p.wait()                                  # ref src/halo_exchange.jl:244: wait before the sends
         ops, staged = [], {}
         for s in sides:
@@ -120,10 +124,20 @@ class HaloExchanger:
             if s in staged:
                 n = staged[s][1].numel()
                 self.buf[s][1][:n].copy_(staged[s][1])
-        if self.host_arrays is None:
+        if self.host_arrays is None and not self.stream_ordered:
             torch.cuda.synchronize(p.device_id)       # receives landed before the unpack kernels read them
+        # (stream-ordered: req.wait() made the current stream — the kernels' stream — wait for the transfers)
         for s in sides:
             self.unpack(s, names)
+
+    def allreduce_min_device(self, scalar):
+        """MIN over the ranks of element 0 of a device vector, in place (RCCL), returned as a float."""
+        torch, dist = self.torch, self.dist
+        if getattr(self, "_scalar_view", None) is None or self._scalar_view[0] != scalar.ptr:
+            self._scalar_view = (scalar.ptr, torch.as_tensor(scalar, device=torch.device("cuda", self.params.device_id)))
+        t = self._scalar_view[1][:1]
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t.item())
 
     def exchange(self, sides, names):
         self.finish(self.start(sides, names))

@@ -206,7 +206,7 @@ class ArmonParameters:
 
     # ref src/parameters.jl:766-778 — backend specific options (like ext/ArmonKokkos.jl:83-87)
     def _init_backend(self, device_id=None, use_fused_sweep=True, exact_arithmetic=False, stream=None,
-                      placement_tries=8, **options):
+                      placement_tries=8, stream_ordered_halo=True, **options):
         """``device_id``: GPU ordinal (default LOCAL_RANK or 0). ``use_fused_sweep``: run each sweep as
         the fused HIP kernel instead of the 5 staged kernels. ``exact_arithmetic=True``: IEEE division/sqrt
         and no FMA contraction in the fused sweep (bit-identical to the staged path and to the CPU oracle);
@@ -224,6 +224,8 @@ class ArmonParameters:
         self.use_fused_sweep = bool(use_fused_sweep) and not self.compare
         self.exact_arithmetic = bool(exact_arithmetic)
         self.placement_tries = int(placement_tries)
+        self.stream_ordered_halo = bool(stream_ordered_halo)   # RCCL: order the exchange on the stream, no host syncs
+        self.shared_stream = False
         self.backend_options = dict(device_id=device_id, use_fused_sweep=self.use_fused_sweep,
                                     exact_arithmetic=self.exact_arithmetic)
         return options
@@ -234,8 +236,28 @@ class ArmonParameters:
         """``create_device(Val(:HIP_native))`` (ref src/parameters.jl:751-755): context on first use."""
         if self._device is None:
             from .device import HIPDevice
-            self._device = HIPDevice(self.device_id, self._stream)
+            stream = self._stream
+            if stream is None and self.use_MPI and self.stream_ordered_halo:
+                stream = self._torch_stream_for_rccl()
+            self._device = HIPDevice(self.device_id, stream)
         return self._device
+
+    def _torch_stream_for_rccl(self):
+        """With the RCCL backend every kernel of this rank runs on ONE torch stream (made current): torch's
+        point-to-point ops then order themselves after the pack kernels and the unpack kernels after the
+        receives on the device, and the halo exchange needs no host synchronisation at all."""
+        try:
+            import torch
+            import torch.distributed as dist
+            if not (dist.is_initialized() and dist.get_backend(self.global_comm) == "nccl"):
+                return None
+            torch.cuda.set_device(self.device_id)
+            self._torch_stream = torch.cuda.Stream(device=self.device_id)
+            torch.cuda.set_stream(self._torch_stream)
+            self.shared_stream = True
+            return self._torch_stream.cuda_stream
+        except ImportError:
+            return None
 
     def fn(self, name):
         """The C-ABI entry point ``armon_hip_<name>`` for this run's data_type (``_f32`` suffix for Float32)."""

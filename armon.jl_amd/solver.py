@@ -475,8 +475,12 @@ def next_time_step(params, grid):
         return
     if grid.dt_pending:
         # the last fused sweep of the previous cycle already reduced the CFL step of this state
-        local_dt = float(grid.dt_scalar.to_host()[0])
         grid.dt_pending = False
+        if grid.comm is not None and getattr(grid.comm, "stream_ordered", False):
+            # RCCL: all_reduce(MIN) in place on the device scalar, one read-back (one host sync per cycle)
+            gdt.update_dt(grid.comm.allreduce_min_device(grid.dt_scalar))
+            return
+        local_dt = float(grid.dt_scalar.to_host()[0])
     else:
         local_dt = local_time_step(params, grid)
     gdt.update_dt(global_min(params, local_dt))
