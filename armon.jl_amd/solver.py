@@ -180,9 +180,10 @@ class BlockGrid:
             best = math.inf
             for rep in range(3):
                 dev.event_record(ARMON_EVENT_SCRATCH)
-                for axis in (Axis.X, Axis.Y):
-                    d = sweep_desc(params, self, axis, dt, dx, emit_dt=axis == Axis.Y)   # as in a cycle
+                for axis in (Axis.X, Axis.Y):          # as in a cycle: X reads set A and writes set B, Y reads B, writes A
+                    d = sweep_desc(params, self, axis, dt, dx, emit_dt=axis == Axis.Y)
                     check(params.fn("sweep")(dev.ctx, C.byref(d)))
+                    self.swap_state()
                 dev.event_record(ARMON_EVENT_SCRATCH + 1)
                 ms = dev.event_elapsed_ms(ARMON_EVENT_SCRATCH, ARMON_EVENT_SCRATCH + 1)
                 if rep:
