@@ -7,14 +7,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"] = str(rank)
     os.environ["WORLD_SIZE"] = str(world)
     os.environ["LOCAL_RANK"] = "0"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     return dist
 
 
@@ -74,16 +79,18 @@ def halo_index_worker(rank, world, port, P, N_global, out_dir):
     dist.destroy_process_group()
 
 
-def gpu_solver_worker(rank, world, port, P, N_global, test, opts, out_dir):
+def gpu_solver_worker(rank, world, port, P, N_global, test, opts, out_dir, backend="gloo"):
     """Tile-decomposed run on the GPU (all ranks share cuda:0, gloo transport with host staging): every rank
     saves its tile so that the parent can compare with the single-process result."""
     import numpy as np
-    dist = _init(rank, world, port)
+    dist = _init(rank, world, port, backend)
     import torch  # noqa: F401  (torch's HIP runtime must be the one the process uses)
     import armon_amd
     params = armon_amd.ArmonParameters(test=test, N=N_global, use_MPI=True, P=P, device_id=0, silent=5,
                                        return_data=True, **opts)
     stats = armon_amd.armon(params)
+    if backend == "nccl":      # the RCCL configuration: kernels on the adopted torch stream, stream-ordered exchange
+        assert params.shared_stream and stats.data.comm.stream_ordered
     host = stats.data.device_to_host(("rho", "u", "v", "E", "p"))
     np.savez(os.path.join(out_dir, f"tile{rank}.npz"), cycles=stats.cycles, dt=stats.last_dt, time=stats.final_time,
              origin=np.array(params.N_origin), n=np.array(params.N),

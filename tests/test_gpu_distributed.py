@@ -32,3 +32,19 @@ def test_two_tiles_equal_one_block(tmp_path, P, N, test, opts, fused):
         nx, ny = (int(v) for v in t["n"])
         for k in ("rho", "u", "v", "E", "p"):
             assert np.array_equal(t[k], full[k][oy:oy + ny, ox:ox + nx]), (r, k)
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["staged", "fused"])
+def test_single_rank_over_rccl_equals_plain_run(tmp_path, fused):
+    """The RCCL configuration (context on an adopted torch stream, stream-ordered exchange, in-place device
+    all-reduce of dt, all-reduce of the conservation sums) with the one rank a single GPU allows."""
+    import armon_amd
+    N, test = (96, 72), "Sod_circ"
+    o = dict(maxcycle=15, use_fused_sweep=fused, exact_arithmetic=True)
+    spawn(dist_workers.gpu_solver_worker, 1, (1, 1), N, test, o, str(tmp_path), "nccl")
+    ref = armon_amd.armon(armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True, **o))
+    host = ref.data.device_to_host(("rho", "u", "v", "E", "p"))
+    t = np.load(tmp_path / "tile0.npz")
+    assert int(t["cycles"]) == ref.cycles and float(t["dt"]) == ref.last_dt and float(t["time"]) == ref.final_time
+    for k in ("rho", "u", "v", "E", "p"):
+        assert np.array_equal(t[k], ref.data.real_view(host[k])), k
