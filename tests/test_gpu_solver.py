@@ -334,3 +334,20 @@ def test_tune_placement_keeps_the_state(oracle):
     _p, stats, host = run("Sod_circ", N=(96, 64), maxcycle=6, placement_tries=1)
     assert stats.cycles == ref.cycles
     assert np.array_equal(oracle.real_view(host["rho"], 96, 64, G), oracle.real_view(ref_fields["rho"], 96, 64, G))
+
+
+@pytest.mark.parametrize("knobs", [dict(ARMON_SWEEP_ALIGN="0"), dict(ARMON_XS_NITER="1"), dict(ARMON_XS_NITER="3"),
+                                   dict(ARMON_XS_NITER="137"), dict(ARMON_Y_SEG="16"), dict(ARMON_Y_SEG="1000")],
+                         ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+def test_tuning_knobs_do_not_change_results(monkeypatch, knobs, exact):
+    """Block/strip origins, strips per wave and rows per run only decide WHO computes a cell: every setting
+    gives the same bits (in both arithmetic flavours)."""
+    opts = dict(N=(333, 77), maxcycle=9, exact_arithmetic=exact)
+    _p, ref_stats, ref = run("Sod_circ", **opts)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    _p, stats, host = run("Sod_circ", **opts)
+    assert stats.cycles == ref_stats.cycles and stats.last_dt == ref_stats.last_dt
+    for k in ("rho", "u", "v", "E", "p"):
+        assert np.array_equal(stats.data.real_view(host[k]), ref_stats.data.real_view(ref[k])), k
