@@ -125,6 +125,7 @@ class BlockGrid:
         self.dt_scalar = dev.zeros(2, dt_)     # device scalar written by the fused dt reduction
         self.dt_pending = False                # True when dt_scalar holds the CFL step of the current state
         self.comm = None                       # set by halo_exchange.setup when use_MPI
+        self.halo_prefetch = None              # (axis, handle) of an exchange posted ahead of its sweep
 
     def ptr(self, name):
         return C.c_void_p(self.data[name].ptr)
@@ -456,7 +457,12 @@ def fused_sweep_overlapped(params, grid, axis, dt, dx, **emit):
     if n < 2 * lag + 1 or not getattr(params, "overlap_halo", True):
         comm.exchange(sides_along(axis), STATE_VARS)
         return fused_sweep(params, grid, axis, dt, dx, **emit)
-    handle = comm.start(sides_along(axis), STATE_VARS)
+    if grid.halo_prefetch is not None and grid.halo_prefetch[0] == axis:
+        handle = grid.halo_prefetch[1]            # posted at the end of the previous cycle (prefetch_halo)
+        grid.halo_prefetch = None
+    else:
+        drain_halo(grid)
+        handle = comm.start(sides_along(axis), STATE_VARS)
     lo, hi = (lag if lo_remote else 0), (n - lag if hi_remote else n)
     fused_sweep(params, grid, axis, dt, dx, out_range=(lo, hi), swap=False, **emit)
     comm.finish(handle)
@@ -465,6 +471,27 @@ def fused_sweep_overlapped(params, grid, axis, dt, dx, **emit):
     if hi_remote:
         fused_sweep(params, grid, axis, dt, dx, out_range=(n - lag, n), swap=False, dt_accumulate=True, **emit)
     grid.swap_state()
+
+
+def prefetch_halo(params, grid):
+    """Post the halo exchange of the NEXT cycle's first sweep right after this cycle's last sweep: it depends on
+    the state only, not on the next dt, so it travels while the dt reduction is folded, all-reduced and read
+    back by the host, and the next cycle's interior sweep can start as soon as its dt is known."""
+    if not (params.use_MPI and params.use_fused_sweep) or grid.comm is None or not getattr(params, "overlap_halo", True):
+        return
+    axis = split_axes(params.axis_splitting, grid.global_dt.cycle + 1)[0][0]
+    remote = [s for s in sides_along(axis) if params.neighbours[s] != PROC_NULL]
+    if not remote or params.N[int(axis) - 1] < 2 * sweep_lag(params) + 1:
+        return
+    drain_halo(grid)
+    grid.halo_prefetch = (axis, grid.comm.start(sides_along(axis), STATE_VARS))
+
+
+def drain_halo(grid):
+    """Complete a prefetched exchange nobody consumed (end of a run, change of plan)."""
+    if grid.halo_prefetch is not None:
+        grid.comm.finish(grid.halo_prefetch[1])
+        grid.halo_prefetch = None
 
 
 # ---- cycle / time loop ---------------------------------------------------------------------------------
@@ -522,6 +549,8 @@ def solver_cycle(params, grid, last_cycle=True):
             last = k == len(sweeps) - 1
             sweep = fused_sweep_overlapped if params.use_MPI else fused_sweep
             sweep(params, grid, axis, dt, dx, emit_p=last and last_cycle, emit_dt=last and not params.cst_dt)
+            if last and not last_cycle:
+                prefetch_halo(params, grid)
         else:
             update_EOS(params, grid, axis)
             if _checkpoint(params, grid, "EOS", axis):
@@ -567,6 +596,7 @@ def time_loop(params, grid):
                 dE = abs(params.initial_energy - energy) / params.initial_energy * 100
                 print(f"Cycle {gdt.cycle:4d}: dt = {gdt.current_dt:.18f}, t = {gdt.time:.18f}, "
                       f"|ΔM| = {dM:#8.6g}%, |ΔE| = {dE:#8.6g}%")
+    drain_halo(grid)
     params.wait()   # "Last fence"
     t2 = _time.perf_counter_ns()
     solve_time = t2 - t1
