@@ -78,6 +78,10 @@ SIGNATURES = {
     "armon_hip_free": (_ci, [_vp, _vp]),
     "armon_hip_memcpy": (_ci, [_vp, _vp, _vp, C.c_size_t, _ci]),
     "armon_hip_memset": (_ci, [_vp, _vp, _ci, C.c_size_t]),
+    "armon_hip_malloc_host": (_ci, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "armon_hip_free_host": (_ci, [_vp, _vp]),
+    "armon_hip_memcpy_async": (_ci, [_vp, _vp, _vp, C.c_size_t, _ci]),
+    "armon_hip_event_sync": (_ci, [_vp, _ci]),
     "armon_hip_stream_copy4": (_ci, [_vp, C.POINTER(_vp * 4), C.POINTER(_vp * 4), C.c_size_t]),
     "armon_hip_timer_start": (_ci, [_vp]),
     "armon_hip_timer_stop": (_ci, [_vp, C.POINTER(_dbl)]),

@@ -179,6 +179,38 @@ int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, i
     return ARMON_OK;
 }
 
+int armon_hip_malloc_host(armon_ctx* ctx, size_t bytes, void** ptr)
+{
+    ARMON_REQUIRE(ctx && ptr, "NULL argument");
+    *ptr = nullptr;
+    if (bytes == 0) return ARMON_OK;
+    ARMON_HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return ARMON_OK;
+}
+
+int armon_hip_free_host(armon_ctx* ctx, void* ptr)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    if (ptr) ARMON_HIP_TRY(hipHostFree(ptr));
+    return ARMON_OK;
+}
+
+int armon_hip_memcpy_async(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    if (bytes == 0) return ARMON_OK;
+    ARMON_REQUIRE(dst && src, "NULL pointer in memcpy_async");
+    hipMemcpyKind k;
+    switch (kind) {
+    case ARMON_MEMCPY_H2D: k = hipMemcpyHostToDevice; break;
+    case ARMON_MEMCPY_D2H: k = hipMemcpyDeviceToHost; break;
+    case ARMON_MEMCPY_D2D: k = hipMemcpyDeviceToDevice; break;
+    default: ARMON_REQUIRE(false, "unknown memcpy kind %d", kind);
+    }
+    ARMON_HIP_TRY(hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
+    return ARMON_OK;
+}
+
 int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes)
 {
     ARMON_REQUIRE(ctx, "ctx is NULL");
@@ -244,6 +276,15 @@ int armon_hip_event_record(armon_ctx* ctx, int slot)
     if (!ctx->ev_pool) ctx->ev_pool = new hipEvent_t[ARMON_HIP_MAX_EVENTS]();
     if (!ctx->ev_pool[slot]) ARMON_HIP_TRY(hipEventCreate(&ctx->ev_pool[slot]));
     ARMON_HIP_TRY(hipEventRecord(ctx->ev_pool[slot], ctx->stream));
+    return ARMON_OK;
+}
+
+int armon_hip_event_sync(armon_ctx* ctx, int slot)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    ARMON_REQUIRE(ctx->ev_pool && slot >= 0 && slot < ARMON_HIP_MAX_EVENTS && ctx->ev_pool[slot],
+                  "event %d was not recorded", slot);
+    ARMON_HIP_TRY(hipEventSynchronize(ctx->ev_pool[slot]));
     return ARMON_OK;
 }
 

@@ -67,6 +67,13 @@ class HIPDevice:
         b = (C.c_void_p * 4)(*[x.ptr for x in dst])
         check(self._L.armon_hip_stream_copy4(self.ctx, C.byref(a), C.byref(b), int(nbytes)))
 
+    def event_sync(self, slot):
+        check(self._L.armon_hip_event_sync(self.ctx, int(slot)))
+
+    def pinned(self, n, dtype=np.float64):
+        """``n`` elements of page-locked host memory as a numpy array (freed with the returned object)."""
+        return PinnedArray(self, n, dtype)
+
     def event_record(self, slot):
         check(self._L.armon_hip_event_record(self.ctx, int(slot)))
 
@@ -162,3 +169,34 @@ class DeviceArray:
 
 def _lib_kind(k):
     return {"H2D": 1, "D2H": 2, "D2D": 3}[k]
+
+
+class PinnedArray:
+    """Page-locked host vector: the landing zone of asynchronous device → host copies."""
+
+    def __init__(self, device, n, dtype=np.float64):
+        self.device, self.dtype = device, np.dtype(dtype)
+        self.nbytes = int(n) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(device._L.armon_hip_malloc_host(device.ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self.ptr), dtype=self.dtype)
+
+    def copy_from_device_async(self, src, n=None, dst_offset=0, src_offset=0):
+        """Enqueue a D2H copy of ``n`` elements on the context's stream; the caller orders it with an event."""
+        n = len(src) - src_offset if n is None else n
+        sz = self.dtype.itemsize
+        check(self.device._L.armon_hip_memcpy_async(self.device.ctx, C.c_void_p(self.ptr + dst_offset * sz),
+                                                    C.c_void_p(src.ptr + src_offset * sz), n * sz, _lib_kind("D2H")))
+
+    def free(self):
+        if self.ptr and self.device.ctx:
+            self.array = None
+            self.device._L.armon_hip_free_host(self.device.ctx, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -130,14 +130,14 @@ class HaloExchanger:
         for s in sides:
             self.unpack(s, names)
 
-    def allreduce_min_device(self, scalar):
-        """MIN over the ranks of element 0 of a device vector, in place (RCCL), returned as a float."""
+    def allreduce_min_device_async(self, scalar):
+        """MIN over the ranks of element 0 of a device vector, in place (RCCL), ordered on the kernels' stream:
+        nothing is waited for on the host."""
         torch, dist = self.torch, self.dist
         if getattr(self, "_scalar_view", None) is None or self._scalar_view[0] != scalar.ptr:
             self._scalar_view = (scalar.ptr, torch.as_tensor(scalar, device=torch.device("cuda", self.params.device_id)))
-        t = self._scalar_view[1][:1]
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        return float(t.item())
+        work = dist.all_reduce(self._scalar_view[1][:1], op=dist.ReduceOp.MIN, group=self.group, async_op=True)
+        work.wait()                # RCCL: makes the current stream (= the kernels' stream) wait, not the host
 
     def exchange(self, sides, names):
         self.finish(self.start(sides, names))

@@ -123,7 +123,8 @@ class BlockGrid:
         self.placement = None                  # report of tune_placement (bench / tests)
         self.global_dt = GlobalTimeStep(params)
         self.dt_scalar = dev.zeros(2, dt_)     # device scalar written by the fused dt reduction
-        self.dt_pending = False                # True when dt_scalar holds the CFL step of the current state
+        self.dt_host = None                    # pinned landing zone of dt_scalar, one slot per cycle parity
+        self.dt_inflight = {}                  # cycle that posted it -> event slot (see post_dt_readback)
         self.comm = None                       # set by halo_exchange.setup when use_MPI
         self.halo_prefetch = None              # (axis, handle) of an exchange posted ahead of its sweep
 
@@ -401,8 +402,6 @@ def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=
     boundaries must already hold the neighbour's (ρ,u,v,E). ``emit_dt``: also reduce the CFL time step
     of the resulting state into ``grid.dt_scalar`` (device)."""
     d = sweep_desc(params, grid, axis, dt, dx, emit_p, emit_c, emit_dt, out_range, dt_accumulate)
-    if emit_dt:
-        grid.dt_pending = True
     with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
         check(params.fn("sweep")(params.device.ctx, C.byref(d)))
     if swap:
@@ -497,21 +496,42 @@ def drain_halo(grid):
 # ---- cycle / time loop ---------------------------------------------------------------------------------
 
 def next_time_step(params, grid):
-    """ref src/reductions.jl:164-199 (grid form)"""
+    """ref src/reductions.jl:164-199 (grid form): CFL step of the current state with the dtCFL kernel, global
+    minimum, ``update_dt!``. Synchronous; the fused path only needs it on its first cycle (see below)."""
     gdt = grid.global_dt
     if params.cst_dt:
         return
-    if grid.dt_pending:
-        # the last fused sweep of the previous cycle already reduced the CFL step of this state
-        grid.dt_pending = False
-        if grid.comm is not None and getattr(grid.comm, "stream_ordered", False):
-            # RCCL: all_reduce(MIN) in place on the device scalar, one read-back (one host sync per cycle)
-            gdt.update_dt(grid.comm.allreduce_min_device(grid.dt_scalar))
-            return
-        local_dt = float(grid.dt_scalar.to_host()[0])
-    else:
-        local_dt = local_time_step(params, grid)
-    gdt.update_dt(global_min(params, local_dt))
+    gdt.update_dt(global_min(params, local_time_step(params, grid)))
+
+
+# The reference consumes a cycle's CFL reduction in the NEXT cycle (one-cycle lag of GlobalTimeStep,
+# ref src/solver_state.jl:89-99,145-166: the MPI_Iallreduce started by cycle n is waited for by cycle n+1).
+# The fused path uses that slack: the last sweep of cycle n-1 reduces L(n), the CFL step of the state cycle n
+# starts from; its read-back is only POSTED then (all-reduce on the device scalar, asynchronous copy into a pinned
+# slot, event), cycle n's sweeps are launched with the dt already known, and L(n) is picked up afterwards for
+# ``update_dt!`` -> cycle n+1. The host never drains the stream: it runs at most one cycle ahead of the GPU.
+DT_EVENT_SLOT = 1012       # event-pool slots 1012, 1013: one per parity of the posting cycle
+
+
+def post_dt_readback(params, grid):
+    """After the last sweep of the current cycle (which reduced the next cycle's L into ``grid.dt_scalar``)."""
+    dev, cycle = params.device, grid.global_dt.cycle
+    if grid.dt_host is None:
+        grid.dt_host = dev.pinned(2, params.data_type)
+    if grid.comm is not None and getattr(grid.comm, "stream_ordered", False):
+        grid.comm.allreduce_min_device_async(grid.dt_scalar)      # RCCL, in place, ordered on the stream
+    grid.dt_host.copy_from_device_async(grid.dt_scalar, n=1, dst_offset=cycle & 1)
+    dev.event_record(DT_EVENT_SLOT + (cycle & 1))
+    grid.dt_inflight[cycle] = DT_EVENT_SLOT + (cycle & 1)
+
+
+def take_dt_readback(params, grid, posted_in_cycle):
+    """Global CFL step posted by ``posted_in_cycle`` (blocks only if the GPU has not got there yet)."""
+    params.device.event_sync(grid.dt_inflight.pop(posted_in_cycle))
+    local_dt = float(grid.dt_host.array[posted_in_cycle & 1])
+    if grid.comm is not None and getattr(grid.comm, "stream_ordered", False):
+        return local_dt                                           # already the minimum over the ranks
+    return global_min(params, local_dt)
 
 
 def _checkpoint(params, grid, label, axis=Axis.X):
@@ -527,13 +547,15 @@ def solver_cycle(params, grid, last_cycle=True):
     ``last_cycle`` (fused path only): materialise p (the reference's saved_vars hold the EOS of the state
     before the last sweep) after this cycle."""
     gdt = grid.global_dt
-    if gdt.cycle == 0 and not grid.dt_pending:
+    deferred = (gdt.cycle - 1) in grid.dt_inflight      # fused path, cycle >= 1: this cycle's dt is already known
+    if gdt.cycle == 0:
         if _checkpoint(params, grid, "init_test"):
             return True
         update_EOS(params, grid)
         if _checkpoint(params, grid, "EOS_init"):
             return True
-    next_time_step(params, grid)
+    if not deferred:
+        next_time_step(params, grid)
     if _checkpoint(params, grid, "time_step"):
         return True
     sweeps = split_axes(params.axis_splitting, gdt.cycle)
@@ -551,6 +573,10 @@ def solver_cycle(params, grid, last_cycle=True):
             sweep(params, grid, axis, dt, dx, emit_p=last and last_cycle, emit_dt=last and not params.cst_dt)
             if last and not last_cycle:
                 prefetch_halo(params, grid)
+            if last and not params.cst_dt:
+                post_dt_readback(params, grid)
+                if deferred:
+                    gdt.update_dt(take_dt_readback(params, grid, gdt.cycle - 1))
         else:
             update_EOS(params, grid, axis)
             if _checkpoint(params, grid, "EOS", axis):
@@ -573,7 +599,7 @@ def solver_cycle(params, grid, last_cycle=True):
 def time_loop(params, grid):
     """ref src/solver.jl:323-403 → (time, dt, cycles, cells_per_ns, solve_time_ns)"""
     grid.global_dt.reset()
-    grid.dt_pending = False
+    grid.dt_inflight.clear()
     gdt = grid.global_dt
     params.wait()
     t1 = _time.perf_counter_ns()

@@ -96,6 +96,13 @@ ARMON_API int armon_hip_malloc(armon_ctx* ctx, size_t bytes, void** ptr);
 ARMON_API int armon_hip_free(armon_ctx* ctx, void* ptr);
 ARMON_API int armon_hip_memcpy(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind); /* async */
 ARMON_API int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes);             /* async */
+/* Pinned host memory + truly asynchronous copies: how the host reads the fused dt/CFL scalar one cycle late
+ * (the reference consumes a cycle's reduction in the NEXT cycle, src/solver_state.jl:89-99,145-166) without ever
+ * draining the stream: memcpy_async into a pinned slot, event_record, and event_sync a cycle later. The host
+ * buffer of memcpy_async must come from malloc_host and stay untouched until the copy's event has completed. */
+ARMON_API int armon_hip_malloc_host(armon_ctx* ctx, size_t bytes, void** ptr);
+ARMON_API int armon_hip_free_host(armon_ctx* ctx, void* ptr);
+ARMON_API int armon_hip_memcpy_async(armon_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
 
 /* Measurement aid (bench.py): plain streaming copy of four arrays into four others in ONE launch —
  * the traffic shape of a fused sweep (4 read + 4 written, 16 B per lane) with no arithmetic. Its rate on
@@ -109,6 +116,7 @@ ARMON_API int armon_hip_stream_copy4(armon_ctx* ctx, const void* const in[4], vo
 #define ARMON_HIP_MAX_EVENTS 1024
 ARMON_API int armon_hip_event_record(armon_ctx* ctx, int slot);
 ARMON_API int armon_hip_event_elapsed_ms(armon_ctx* ctx, int a, int b, double* elapsed_ms);
+ARMON_API int armon_hip_event_sync(armon_ctx* ctx, int slot);                   /* host waits for that event only */
 ARMON_API int armon_hip_timer_start(armon_ctx* ctx);
 ARMON_API int armon_hip_timer_stop(armon_ctx* ctx, double* elapsed_ms);        /* synchronises on the stop event */
 
