@@ -569,6 +569,26 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     return check_launch("sweep_x_dpp");
 }
 
+// Rows per run of the Y march. A run re-reads 2·LAG halo rows, so long runs are cheaper per cell, but the grid
+// must still fill the device evenly: at 2 waves/SIMD the chip holds n_cu·8 waves, and a grid of 1.06 such rounds
+// takes 2. Pick the length that minimises rounds × (rows + halo) (A/B on 4096²: 32 rows -16 % against 128; 8192²:
+// 64 rows -4 %; 16384²: 128).
+int y_run_length(int n_cu, int64_t nx, int64_t ny)
+{
+    const int64_t slots = (int64_t)n_cu * 8, cols = (nx + 16 + kYBlock - 1) / kYBlock;
+    int best = 128;
+    double best_cost = 1e300;
+    for (int seg : {128, 96, 64, 32}) {
+        const int64_t waves = cols * ((ny + seg - 1) / seg) * (kYBlock / 64);
+        const double cost = (double)((waves + slots - 1) / slots) * (seg + 8);
+        if (cost < best_cost * 0.97) {       // prefer the longer run unless the shorter one clearly wins
+            best_cost = cost;
+            best = seg;
+        }
+    }
+    return best;
+}
+
 // Upper bound of the number of workgroups any form launches for this block (sizes the partials buffer).
 int64_t max_blocks(const sweep_args& a)
 {
@@ -667,7 +687,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.c_out = d->c_out;
     const char* seg_s = getenv("ARMON_Y_SEG");                       // tuning knob, read per launch (A/B runs)
     const int seg_y_env = seg_s ? atoi(seg_s) : 0;
-    a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : 128);
+    a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : y_run_length(ctx->n_cu, d->nx, n_axis));
     a.x_kernel = d->x_kernel;
     a.o_lo = 0;
     a.o_hi = n_axis;
