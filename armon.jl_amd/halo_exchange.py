@@ -17,7 +17,6 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
 from ._lib import check
 from .blocking import Side
 from .parameters import PROC_NULL

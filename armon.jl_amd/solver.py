@@ -8,13 +8,11 @@ through the C ABI of libarmon_hip.so; nothing here computes on the host.
 """
 import ctypes as C
 import math
-import os
 import time as _time
 from dataclasses import dataclass
 
 import numpy as np
 
-from . import _lib
 from ._lib import BlockDataPtrs, FIELDS, SweepDesc, check, solver_error
 from .blocking import Axis, Side, first_side, last_side, sides_along
 from .parameters import LIMITERS, PROC_NULL, PROJECTIONS, SCHEMES

@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import armon_amd
 from armon_amd.blocking import Axis
-from armon_amd.solver import BlockGrid, fused_sweep, init_test, update_EOS
+from armon_amd.solver import BlockGrid, fused_sweep, init_test
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=16384)
