@@ -308,9 +308,19 @@ k_sweep_y(sweep_args a)
 constexpr int kXSRows = 4;
 constexpr int kXSNiter = 2;      // strips per wave (A/B over 1..137 with tools/ab_sweep.py: short-lived waves keep the global access order sequential)
 
+constexpr int kXSlots = 4096;    // dt/CFL tracking of the X sweep: slots the waves fold their maxima into
+
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
+{
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v)
+{
+    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
 template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
-__global__ void __launch_bounds__(64 * kXSRows)
-k_sweep_x_dpp(sweep_args a, int niter)
+__device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 {
     using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, K, real>;
     using St = fused::Strip<K, real>;
@@ -431,9 +441,26 @@ k_sweep_x_dpp(sweep_args a, int niter)
             do_strip(std::integral_constant<int, 1>{}, it + 1);
         }
     }
-    if (TRACK)
-        cfl_block_store<kXSRows>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x,
-                                 threadIdx.y * 64 + threadIdx.x);
+    // The waves of this kernel are short-lived (2 strips): a block-level LDS reduction + one partial per block
+    // cost more than the strips themselves (282k blocks at 16384²: +1.1 ms). Each wave folds its two maxima
+    // into one of kXSlots slots with an integer atomic max instead (bit patterns of non-negative IEEE numbers
+    // are ordered like the numbers; max is order-independent, so the result stays deterministic).
+    if (TRACK) {
+        const real au = red::wave_reduce<red::op_max>(cfl.au), av = red::wave_reduce<red::op_max>(cfl.av);
+        if (lane == 0) {
+            const int64_t wave_id = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kXSRows + threadIdx.y;
+            real* slot = a.partials + 2 * (wave_id & (kXSlots - 1));
+            atomic_max_nonneg(slot, au);
+            atomic_max_nonneg(slot + 1, av);
+        }
+    }
+}
+
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
+__global__ void __launch_bounds__(64 * kXSRows)
+k_sweep_x_dpp(sweep_args a, int niter)
+{
+    sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK>(a, niter);
 }
 
 // ---- X sweep, LDS-transposed march (alternative form) -----------------------------------------------------
@@ -560,6 +587,11 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
     dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
     *n_blocks = (int64_t)grid.x * grid.y;
+    if (TRACK) {
+        if (hipMemsetAsync(a.partials, 0, 2 * kXSlots * sizeof(real), ctx->stream) != hipSuccess)
+            return check_launch("sweep_x_dpp (slots)");
+        *n_blocks = kXSlots;
+    }
     if (k1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
                            grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
@@ -596,7 +628,8 @@ int64_t max_blocks(const sweep_args& a)
     const int64_t bx_lds = (a.nx + a.seg - 1) / a.seg * ((a.ny + kXRows - 1) / kXRows);
     const int64_t bx_dpp = ((a.nx + 8) / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows);     // niter >= 1, K = 1, LAG = 4
     int64_t m = by > bx_lds ? by : bx_lds;
-    return m > bx_dpp ? m : bx_dpp;
+    m = m > bx_dpp ? m : bx_dpp;
+    return m > kXSlots ? m : kXSlots;
 }
 
 template <class PIPE>

@@ -25,6 +25,7 @@ ap.add_argument("--exact", action="store_true")
 ap.add_argument("--scheme", default="GAD")
 ap.add_argument("--projection", default="euler_2nd")
 ap.add_argument("--f32", action="store_true")
+ap.add_argument("--track-x", action="store_true", help="fused dt/CFL reduction on the X sweep too (X-last splittings)")
 ap.add_argument("--env", default="", help="per-build env: name:KEY=VAL,KEY=VAL;name2:... applied around that build's launches")
 ap.add_argument("--gap-ms", type=float, default=0., help="idle time before every launch (clock/power recovery experiments)")
 ap.add_argument("--copy", action="store_true", help="also time armon_hip_stream_copy4 on the same arrays (same bytes, no arithmetic)")
@@ -58,7 +59,7 @@ res = {}
 knobs = sorted({k for e in envs.values() for k in e})
 for r in range(args.rounds + 2):
     for axis in (Axis.X, Axis.Y):
-        d = sweep_desc(params, grid, axis, dt, dx, emit_dt=axis == Axis.Y)
+        d = sweep_desc(params, grid, axis, dt, dx, emit_dt=axis == Axis.Y or args.track_x)
         for name, L, ctx in builds:
             for k in knobs:
                 os.environ.pop(k, None)
