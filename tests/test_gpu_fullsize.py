@@ -1,0 +1,77 @@
+"""Parity at BASELINE.json's full size (Sod 16384², the bench workload) through size-independent properties:
+
+* axis invariance (ref test/convergence.jl:31-64): Sod depends on x only, so every one of the 16384 rows must hold
+  the same bits — both sweeps, every workgroup, every strip/run boundary and the ghost handling are exercised;
+* that common row must equal the CPU oracle run on a 16384×8 strip of the same cell size (bit for bit in exact
+  arithmetic, staged and fused; within the tuned tolerance otherwise), together with dt, time and cycle count;
+* conservation of mass and energy (ref test/conservation.jl) to 1e-11 relative over the run.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, G, CYCLES = 16384, 4, 5
+NAMES = ("rho", "u", "v", "E", "p")
+
+
+@pytest.fixture(scope="module")
+def oracle_strip(oracle):
+    """The oracle on 16384×8 cells of the same size (domain 1 × 8/16384): its rows are the full problem's rows."""
+    run, f = oracle.solve(test="Sod", N=(N, 8), domain_size=(1., 8. / N), maxcycle=CYCLES, threads=8)
+    rows = {k: oracle.real_view(f[k], N, 8, G) for k in NAMES}
+    for k in NAMES:
+        assert np.array_equal(rows[k], np.broadcast_to(rows[k][0:1], rows[k].shape)), k
+    return run, {k: rows[k][0].copy() for k in NAMES}
+
+
+@pytest.mark.parametrize("mode", ["fused-exact", "staged", "fused-tuned"])
+def test_sod_16384_rows_identical_and_equal_to_the_oracle(oracle_strip, mode):
+    import armon_amd
+    from armon_amd.solver import BlockGrid, conservation_vars, init_test, time_loop
+    orun, orow = oracle_strip
+    params = armon_amd.ArmonParameters(test="Sod", N=(N, N), maxcycle=CYCLES, silent=5,
+                                       use_fused_sweep=mode != "staged", exact_arithmetic=mode != "fused-tuned")
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    if mode != "staged":
+        assert grid.placement and grid.placement["tries"] >= 2          # the placement tuning ran at this size
+    m0, e0 = conservation_vars(params, grid)
+    time_, dt, cycles, _, _ = time_loop(params, grid)
+    m1, e1 = conservation_vars(params, grid)
+    assert abs(m1 - m0) <= 1e-11 * abs(m0) and abs(e1 - e0) <= 1e-11 * abs(e0)
+    assert cycles == orun.cycles == CYCLES
+    exact = mode != "fused-tuned"
+    if exact:
+        assert dt == orun.last_dt and time_ == orun.final_time
+    else:
+        assert abs(dt - orun.last_dt) <= 1e-12 * orun.last_dt
+    for k in NAMES:
+        a = grid.real_view(grid.data[k].to_host())
+        assert np.array_equal(a, np.broadcast_to(a[0:1], a.shape)), f"{k}: rows differ"
+        if exact:
+            assert np.array_equal(a[0], orow[k]), k
+        else:
+            assert np.abs(a[0] - orow[k]).max() <= 1e-11 * np.abs(orow[k]).max(), k
+        del a
+
+
+@pytest.mark.parametrize("test", ["Sod_y", "Bizarrium"])
+def test_other_cases_16384_fused_exact(oracle, test):
+    """Sod_y varies along y only (columns identical, oracle strip 8×16384); Bizarrium along x with its own EOS."""
+    import armon_amd
+    along_x = test != "Sod_y"
+    ds = {"Sod_y": (8. / N, 1.), "Bizarrium": (1., 8. / N)}[test]
+    n_strip = (N, 8) if along_x else (8, N)
+    orun, f = oracle.solve(test=test, N=n_strip, domain_size=ds, maxcycle=CYCLES, threads=8)
+    params = armon_amd.ArmonParameters(test=test, N=(N, N), maxcycle=CYCLES, silent=5, exact_arithmetic=True,
+                                       return_data=True)
+    stats = armon_amd.armon(params)
+    assert stats.cycles == orun.cycles and stats.last_dt == orun.last_dt and stats.final_time == orun.final_time
+    for k in NAMES:
+        a = stats.data.real_view(stats.data.data[k].to_host())
+        o = oracle.real_view(f[k], n_strip[0], n_strip[1], G)
+        line = a[0:1] if along_x else a[:, 0:1]
+        assert np.array_equal(a, np.broadcast_to(line, a.shape)), f"{k}: lines differ"
+        assert np.array_equal(line.ravel(), (o[0] if along_x else o[:, 0])), k
+        del a
