@@ -71,6 +71,12 @@ def test_reference_golden_unasserted_cases(test, fused):
     ("Sod_circ", (40, 40), dict(cst_dt=True, Dt=1e-3, maxcycle=15)),
     ("Sod_circ", (40, 40), dict(scheme="Godunov", projection="euler", nghost=2, maxcycle=15)),
     ("Sod_circ", (40, 40), dict(nghost=5, maxcycle=15)),
+    # several workgroups / strips / runs per axis, odd sizes, odd and wide ghost layers (origin alignment paths)
+    ("Sod_circ", (517, 263), dict(nghost=5, maxcycle=8)),
+    ("Sod_circ", (1031, 130), dict(nghost=6, maxcycle=8)),
+    ("Sedov", (300, 301), dict(nghost=7, maxcycle=8)),
+    ("Sod_circ", (770, 515), dict(axis_splitting="Godunov", maxcycle=7)),      # X-last cycles: X sweep dt tracking
+    ("Bizarrium", (513, 129), dict(axis_splitting="X_only", maxcycle=8)),
 ])
 def test_bit_exact_against_oracle(oracle, test, N, opts, fused):
     """Whole-solver parity: every real cell of ρ,u,v,E,p, the cycle count and dt are identical."""
@@ -168,6 +174,10 @@ FAST_CASES = [
     ("Sod_circ", (48, 48), dict(riemann_limiter="no_limiter", maxcycle=40)),
     ("Sod_circ", (48, 40), dict(axis_splitting="Strang", maxcycle=20)),
     ("Sod_circ", (40, 40), dict(scheme="Godunov", projection="euler", nghost=2, maxcycle=20)),
+    ("Sod_circ", (517, 263), dict(nghost=5, maxcycle=8)),
+    ("Sedov", (300, 301), dict(nghost=7, maxcycle=8)),
+    ("Sod_circ", (770, 515), dict(axis_splitting="Godunov", maxcycle=7)),
+    ("Bizarrium", (513, 129), dict(axis_splitting="X_only", maxcycle=8)),
 ]
 
 
