@@ -13,6 +13,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
+from . import _lib
 from ._lib import BlockDataPtrs, FIELDS, SweepDesc, check, solver_error
 from .blocking import Axis, Side, first_side, last_side, sides_along
 from .parameters import LIMITERS, PROC_NULL, PROJECTIONS, SCHEMES
@@ -166,8 +167,16 @@ class BlockGrid:
         dt = 1e-3 * dx                    # any small step: the arithmetic does not depend on the data
         n, dt_ = self.data["rho"].n, self.data["rho"].dtype
         pool = [self.data[f] for f in STATE_VARS] + [self.alt[f] for f in STATE_VARS]
-        pool += [dev.empty(n, dt_) for _ in range(spare)]
-        master = {f: dev.empty(n, dt_) for f in STATE_VARS}     # the state is parked here while roles move around
+        extra = []
+        try:
+            for _ in range(spare + 4):
+                extra.append(dev.empty(n, dt_))
+        except _lib.SolverException:          # not enough memory after all: keep the placement we have
+            for v in extra:
+                v.free()
+            return None
+        pool += extra[:spare]
+        master = dict(zip(STATE_VARS, extra[spare:]))           # the state is parked here while roles move around
         for f in STATE_VARS:
             master[f].copy_from_device(self.data[f])
 
