@@ -53,6 +53,7 @@ def test_f32_reference_golden_sod_family(test, mode):
     ("Bizarrium", (64, 32), dict(maxcycle=30)),
     ("Sod_circ", (48, 48), dict(scheme="Godunov", projection="euler", nghost=2, maxcycle=25)),
     ("Sod_circ", (48, 40), dict(axis_splitting="Strang", riemann_limiter="superbee", maxcycle=15)),
+    ("Sod_circ", (517, 263), dict(axis_splitting="Godunov", nghost=5, maxcycle=8)),     # many workgroups, X-last cycles
 ])
 def test_f32_bit_exact_against_f32_oracle(oracle, test, N, opts, mode):
     params, stats, host = run32(test, N=N, **mode, **opts)
