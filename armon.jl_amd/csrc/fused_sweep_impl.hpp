@@ -124,6 +124,19 @@ __device__ __forceinline__ float buf_load<float>(rsrc_t r, unsigned voff, unsign
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxLoad));
 }
+__device__ __forceinline__ float2 buf_load2(rsrc_t r, unsigned voff, unsigned soff)      // fp32 pairs only
+{
+    // NB: cast the whole vector. Extracting .x/.y from the builtin's <2 x i32> result makes hipcc (ROCm 7.2) narrow
+    // the load to one dword and hand element 0 to both users (seen in the ISA: buffer_load_dword + op_sel_hi:[0,1]).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxLoad));
+    return float2{v.x, v.y};
+}
+__device__ __forceinline__ void buf_store2(rsrc_t r, unsigned voff, unsigned soff, float x, float y)
+{
+    const v2u v = {__builtin_bit_cast(unsigned int, x), __builtin_bit_cast(unsigned int, y)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, kAuxStore);
+}
 __device__ __forceinline__ void buf_store(rsrc_t r, unsigned voff, unsigned soff, double x)
 {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, soff, kAuxStore);
@@ -278,6 +291,132 @@ k_sweep_y(sweep_args a)
                 buf_store(w_E, colb, so_off, out.E);
             }
             if (TRACK) cfl.add(out.ut, out.ua, c_lag);      // Y sweep: ut = u, ua = v
+        }
+        so_off += pitchb;
+    };
+    auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 8
+        for (int t = t0; t < t1; t += 8)
+            static_for(std::make_integer_sequence<int, 8>{}, [&](auto ph) { step(ph, checked, jb + t + decltype(ph)::value); });
+    };
+
+    const int T = je - jb;                                   // steps of the run
+    const int T8 = (T + 7) & ~7;                             // … padded to the unroll
+    const int P = (2 * LAG + 7) & ~7;                        // after P steps every step emits a valid cell
+    // last step (exclusive) whose prefetch needs neither mirroring nor clamping and whose store is valid
+    const int plain_end = (a.bc_high && ny < je ? ny : je) - jb - PF;
+    int M = (T < plain_end ? T : plain_end) & ~7;
+    if (M < P || (a.emit & 3)) M = P;                        // p/c output: everything through the checked form
+
+    static_for(std::make_integer_sequence<int, PF>{}, [&](auto k) { load(k, std::true_type{}); });
+    run(std::true_type{}, 0, P < T8 ? P : T8);
+    run(std::false_type{}, P, M);
+    run(std::true_type{}, M, T8);
+
+    if (TRACK) cfl_block_store<kYBlock / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
+}
+
+// Two columns per lane: the fp32 form of the Y march. With 4-B elements one column per lane moves only 256 B per
+// wave and instruction; two adjacent columns per lane (8-B accesses, two independent pipelines = twice the ILP at
+// the register cost of one fp64 pipeline) restore the 512-B row segments of the fp64 kernel.
+template <class PIPE, bool TRACK>
+__global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
+k_sweep_y2(sweep_args a)
+{
+    constexpr int LAG = PIPE::LAG;
+    constexpr int PF = ARMON_Y_PF;   // rows in flight per lane, ahead of the march
+    const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
+    // Two adjacent columns per lane (nx, g and a.xshift are even here): xr, xr + 1; 8-B accesses.
+    const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x) * 2 - a.xshift;
+    const bool active = xr >= 0 && xr < nx;
+    const int x = active ? xr : (xr < 0 ? 0 : nx - 2);   // idle lanes shadow an edge pair and never store
+    const int o_hi = (int)a.o_hi;
+    const int o0 = (int)a.o_lo + (int)blockIdx.y * a.seg;
+    const int o1 = (o0 + a.seg < o_hi) ? o0 + a.seg : o_hi;
+    const int jb = o0 - LAG, je = o1 + LAG;
+
+    // Descriptors are based at the first row this run touches, so every scalar row offset is a small
+    // non-negative 32-bit number whatever the size of the arrays (mirrored rows lie inside the run).
+    const unsigned colb = (unsigned)(x + g) * (unsigned)sizeof(real);
+    const unsigned pitchb = (unsigned)a.row_len * (unsigned)sizeof(real);
+    const int64_t in_base = (int64_t)(jb + g) * a.row_len, out_base = (int64_t)(o0 + g) * a.row_len;
+    const rsrc_t r_rho = make_rsrc(a.rho_in + in_base), r_ua = make_rsrc(a.ua_in + in_base);
+    const rsrc_t r_ut = make_rsrc(a.ut_in + in_base), r_E = make_rsrc(a.E_in + in_base);
+    const rsrc_t w_rho = make_rsrc(a.rho_out + out_base), w_ua = make_rsrc(a.ua_out + out_base);
+    const rsrc_t w_ut = make_rsrc(a.ut_out + out_base), w_E = make_rsrc(a.E_out + out_base);
+
+    PIPE pipe[2] = {PIPE(a.dt, a.dx, a.gamma), PIPE(a.dt, a.dx, a.gamma)};
+    cfl_track cfl;
+
+    int lj = jb;                     // next row to load and its offset from the run's first row
+    unsigned lo_off = 0;
+    unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;     // row j - LAG relative to row o0 (wraps until valid)
+
+    // The state of row lj is loaded straight into the pipeline's cell ring, slot lj mod 8, PF steps before
+    // the march reaches it. CHECKED steps handle everything (mirrored / clamped loads, masked stores,
+    // p/c output); the steady state of a run uses the unchecked form: plain loads, unconditional stores.
+    auto load = [&](auto slot, auto checked) {
+        constexpr int K = decltype(slot)::value & 7;
+        constexpr bool CHECKED = decltype(checked)::value;
+        auto& d0 = pipe[0].c[K];
+        auto& d1 = pipe[1].c[K];
+        auto put = [&](unsigned off, real fa, real ft) {
+            const float2 r = buf_load2(r_rho, colb, off), u = buf_load2(r_ua, colb, off);
+            const float2 v = buf_load2(r_ut, colb, off), e = buf_load2(r_E, colb, off);
+            d0.rho = r.x; d1.rho = r.y;
+            d0.ua = u.x * fa; d1.ua = u.y * fa;
+            d0.ut = v.x * ft; d1.ut = v.y * ft;
+            d0.E = e.x; d1.E = e.y;
+        };
+        if (CHECKED) {
+            const bool m_lo = lj < 0 && a.bc_low, m_hi = lj >= ny && a.bc_high;     // uniform, rare
+            // physical boundary: mirror of the inside (ref src/halo_exchange.jl:2-29)
+            const int src = m_lo ? -1 - lj : (m_hi ? 2 * ny - 1 - lj : lj);
+            const unsigned off = (unsigned)(src - jb) * pitchb;
+            const real fa = m_lo ? a.fa_low : (m_hi ? a.fa_high : real(1));
+            const real ft = m_lo ? a.ft_low : (m_hi ? a.ft_high : real(1));
+            put(off, fa, ft);
+            if (lj + 1 < je) {       // stay on the last row once the run is exhausted (padding steps)
+                lj++;
+                lo_off += pitchb;
+            }
+        } else {
+            const float2 r = buf_load2(r_rho, colb, lo_off), u = buf_load2(r_ua, colb, lo_off);
+            const float2 v = buf_load2(r_ut, colb, lo_off), e = buf_load2(r_E, colb, lo_off);
+            d0.rho = r.x; d1.rho = r.y;
+            d0.ua = u.x; d1.ua = u.y;
+            d0.ut = v.x; d1.ut = v.y;
+            d0.E = e.x; d1.E = e.y;
+            lj++;
+            lo_off += pitchb;
+        }
+    };
+    using std::integral_constant;
+    auto step = [&](auto ph, auto checked, int j) {
+        constexpr int PH8 = decltype(ph)::value;
+        constexpr bool CHECKED = decltype(checked)::value;
+        load(integral_constant<int, PH8 + PF>{}, checked);   // row j + PF → slot (j + PF) mod 8
+        real p0, c0, cl0, p1, c1, cl1;
+        const fused::Out4<real> out0 = pipe[0].template advance<true, PH8>(p0, c0, cl0);
+        const fused::Out4<real> out1 = pipe[1].template advance<true, PH8>(p1, c1, cl1);
+        const int o = j - LAG;
+        if (CHECKED) {
+            if (a.emit && j >= o0 && j < o1 && active) {
+                const unsigned off = so_off + LAG * pitchb;
+                if (a.emit & 1) buf_store2(make_rsrc(a.p_out + out_base), colb, off, p0, p1);
+                if (a.emit & 2) buf_store2(make_rsrc(a.c_out + out_base), colb, off, c0, c1);
+            }
+        }
+        if (!CHECKED || (o >= o0 && o < o1)) {
+            if (active) {
+                buf_store2(w_rho, colb, so_off, out0.rho, out1.rho);
+                buf_store2(w_ua, colb, so_off, out0.ua, out1.ua);
+                buf_store2(w_ut, colb, so_off, out0.ut, out1.ut);
+                buf_store2(w_E, colb, so_off, out0.E, out1.E);
+            }
+            if (TRACK) {                                     // Y sweep: ut = u, ua = v
+                cfl.add(out0.ut, out0.ua, cl0);
+                cfl.add(out1.ut, out1.ua, cl1);
+            }
         }
         so_off += pitchb;
     };
@@ -566,6 +705,15 @@ template <class PIPE, bool TRACK>
 int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
 {
     const int64_t n_out = a.o_hi - a.o_lo;
+    if constexpr (std::is_same<real, float>::value) {
+        // fp32: two columns per lane when every row is 8-B aligned (even pitch and ghost width)
+        if (axis == ARMON_AXIS_Y && a.nx % 2 == 0 && a.g % 2 == 0 && a.nx >= 2 && !getenv("ARMON_Y_COLS1")) {
+            dim3 grid((unsigned)((a.nx + a.xshift + 2 * kYBlock - 1) / (2 * kYBlock)), (unsigned)((n_out + a.seg - 1) / a.seg));
+            *n_blocks = (int64_t)grid.x * grid.y;
+            hipLaunchKernelGGL((k_sweep_y2<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
+            return check_launch("sweep_y2");
+        }
+    }
     if (axis == ARMON_AXIS_Y) {
         dim3 grid((unsigned)((a.nx + a.xshift + kYBlock - 1) / kYBlock), (unsigned)((n_out + a.seg - 1) / a.seg));
         *n_blocks = (int64_t)grid.x * grid.y;
