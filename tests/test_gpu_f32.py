@@ -113,14 +113,14 @@ def test_f32_staged_kernels_against_oracle(oracle):
     dev.close()
 
 
-@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
-def test_f32_two_column_y_march_equals_the_one_column_form(monkeypatch, exact):
-    """The fp32 Y sweep runs two columns per lane (8-B accesses) when rows are 8-B aligned; it must give the bits
-    of the one-column kernel (forced with ARMON_Y_COLS1, and taken anyway for odd sizes)."""
-    opts = dict(N=(334, 77), maxcycle=9, use_fused_sweep=True, exact_arithmetic=exact)
-    _p, s2, h2 = run32("Sod_circ", **opts)
+@pytest.mark.parametrize("test,N", [("Sod_circ", (334, 77)), ("Sedov", (120, 200)), ("Bizarrium", (256, 64))])
+def test_f32_two_column_y_march_equals_the_one_column_form(monkeypatch, test, N):
+    """The tuned fp32 Y sweep runs two columns per lane (8-B accesses) when rows are 8-B aligned; it must give the
+    bits of the one-column kernel (forced with ARMON_Y_COLS1, and taken anyway for odd sizes)."""
+    opts = dict(N=N, maxcycle=9, use_fused_sweep=True, exact_arithmetic=False)
+    _p, s2, h2 = run32(test, **opts)
     monkeypatch.setenv("ARMON_Y_COLS1", "1")
-    _p, s1, h1 = run32("Sod_circ", **opts)
+    _p, s1, h1 = run32(test, **opts)
     assert s1.cycles == s2.cycles and s1.last_dt == s2.last_dt
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(h1[k], h2[k]), k
