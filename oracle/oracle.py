@@ -63,6 +63,8 @@ Run32 = _run_struct(C.c_float)
 def build(native=False, force=False, f32=False):
     """Compile the oracle with gcc (seconds). ``native`` → -march=native into its own file; ``f32`` → the
     fp32 build of the same source (libarmon_oracle_f32.so)."""
+    if os.environ.get("ARMON_ORACLE_LIB") and not f32:      # e.g. the sanitizer build (oracle/Makefile)
+        return os.path.abspath(os.environ["ARMON_ORACLE_LIB"])
     out = "libarmon_oracle_native.so" if native else "libarmon_oracle.so"
     if f32:
         out = "libarmon_oracle_f32.so"
