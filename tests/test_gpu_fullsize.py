@@ -75,3 +75,23 @@ def test_other_cases_16384_fused_exact(oracle, test):
         assert np.array_equal(a, np.broadcast_to(line, a.shape)), f"{k}: lines differ"
         assert np.array_equal(line.ravel(), (o[0] if along_x else o[:, 0])), k
         del a
+
+
+def test_sod_4096_full_run_to_maxtime():
+    """A whole physical run (t = 0.2, ≈1900 cycles, tuned arithmetic, deferred dt read-back all the way): mass and
+    energy conserved to 1e-12 relative (ref test/conservation.jl's bound is 1e-12 absolute at 100²), rows identical."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, conservation_vars, init_test, time_loop
+    n = 4096
+    params = armon_amd.ArmonParameters(test="Sod", N=(n, n), silent=5)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    m0, e0 = conservation_vars(params, grid)
+    time_, dt, cycles, _, _ = time_loop(params, grid)
+    m1, e1 = conservation_vars(params, grid)
+    assert time_ >= 0.2 and 1800 < cycles < 2000 and 0 < dt < 1e-3
+    assert abs(m1 - m0) <= 1e-12 * m0 and abs(e1 - e0) <= 1e-12 * e0
+    for k in ("rho", "u", "E"):
+        a = grid.real_view(grid.data[k].to_host())
+        assert np.isfinite(a).all() and np.array_equal(a, np.broadcast_to(a[0:1], a.shape)), k
+    assert not grid.real_view(grid.data["v"].to_host()).any()
