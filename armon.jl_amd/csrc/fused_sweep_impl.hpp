@@ -1,4 +1,4 @@
-// fused_sweep.hip — armon_hip_sweep: one directional sweep of solver_cycle (ref src/solver.jl:300-316)
+// fused_sweep_impl.hpp — armon_hip_sweep: one directional sweep of solver_cycle (ref src/solver.jl:300-316)
 // as ONE kernel launch: EOS → boundary mirror → fluxes → cell update → advection → projection, reading
 // ρ,u,v,E once and writing them once (64 B per cell instead of the 352 B of the five staged passes),
 // optionally followed by the dt/CFL reduction of the next cycle (ref src/reductions.jl:2-53) on the state
@@ -7,13 +7,17 @@
 // Kernels:
 //  * Y sweep (k_sweep_y): lane ↔ column, the register pipeline of sweep_pipeline.hpp marches along y.
 //    Rows are x-contiguous, so every step is one fully coalesced row segment per wave; no LDS. A
-//    workgroup owns 256 columns × one run of rows; 4 rows per lane are kept in flight.
+//    workgroup owns 256 columns × one run of rows; 4 rows per lane are kept in flight. fp32 (tuned) uses
+//    k_sweep_y2: two adjacent columns per lane, so that a wave still moves 512 B per row and array.
 //  * X sweep, spatial form (k_sweep_x_dpp, default): lane ↔ cell(s) of a row, neighbours fetched with
 //    DPP wavefront shifts (sweep_spatial.hpp); no LDS, no barrier, coalesced 16-B accesses.
 //  * X sweep, LDS-transposed march (k_sweep_x_lds, alternative form kept for A/B measurements): a wave
 //    transposes 64-row × 8-column tiles through LDS and each lane marches along its row with the same
 //    pipeline as the Y sweep.
-// Redundant work is confined to the LAG (≤4) cells at both ends of a run / strip.
+// Redundant work is confined to the LAG (≤4) cells at both ends of a run / strip. Block and strip origins are
+// aligned to the 64-B sectors of the ghosted rows, stores are non-temporal (DESIGN.md §4.2 has the A/B numbers).
+// Tuning knobs read per launch, for tools/ab_sweep.py and the parity tests: ARMON_SWEEP_ALIGN, ARMON_XS_NITER,
+// ARMON_Y_SEG, ARMON_Y_COLS1; compile-time: ARMON_NT, ARMON_Y_PF, ARMON_Y_WAVES, ARMON_PROBE_NOCOMPUTE.
 #pragma once
 #include "common.hpp"
 #include "reduce.hpp"
@@ -26,7 +30,7 @@
 
 using namespace armon;
 
-// This file is compiled twice: fused_sweep_f64.hip (real = real, armon_hip_sweep) and fused_sweep_f32.hip
+// This file is compiled twice: fused_sweep_f64.hip (real = double, armon_hip_sweep) and fused_sweep_f32.hip
 // (real = float, armon_hip_sweep_f32); everything else lives in the translation unit's anonymous namespace.
 #ifndef ARMON_SWEEP_REAL
 #error "include through fused_sweep_f64.hip / fused_sweep_f32.hip"
