@@ -95,3 +95,27 @@ def test_sod_4096_full_run_to_maxtime():
         a = grid.real_view(grid.data[k].to_host())
         assert np.isfinite(a).all() and np.array_equal(a, np.broadcast_to(a[0:1], a.shape)), k
     assert not grid.real_view(grid.data["v"].to_host()).any()
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+def test_sod_16384_f32(oracle, exact):
+    """Float32 at full size (the tuned flavour runs the two-column Y march): rows identical; equal to the fp32 oracle
+    strip bit for bit in exact arithmetic, within 2e-5 of the field maximum (≈170 eps32) otherwise."""
+    import armon_amd
+    orun, f = oracle.solve(test="Sod", N=(N, 8), domain_size=(1., 8. / N), maxcycle=CYCLES, threads=8, data_type=np.float32)
+    params = armon_amd.ArmonParameters(test="Sod", N=(N, N), maxcycle=CYCLES, silent=5, data_type="float32",
+                                       exact_arithmetic=exact, return_data=True)
+    stats = armon_amd.armon(params)
+    assert stats.cycles == orun.cycles
+    if exact:
+        assert np.float32(stats.last_dt) == np.float32(orun.last_dt)
+    for k in NAMES:
+        a = stats.data.real_view(stats.data.data[k].to_host())
+        assert a.dtype == np.float32
+        assert np.array_equal(a, np.broadcast_to(a[0:1], a.shape)), f"{k}: rows differ"
+        o = oracle.real_view(f[k], N, 8, G)[0]
+        if exact:
+            assert np.array_equal(a[0], o), k
+        else:
+            assert np.abs(a[0].astype(np.float64) - o).max() <= 2e-5 * np.abs(o).max(), k
+        del a
