@@ -105,6 +105,8 @@ SIGNATURES = {
                                   C.POINTER(_i64 * 2), C.POINTER(_dbl * 2), C.POINTER(_dbl * 2),
                                   _dbl, C.POINTER(BlockDataPtrs)]),
     "armon_hip_sweep": (_ci, [_vp, C.POINTER(SweepDesc)]),
+    "armon_hip_tune_placement": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc), C.POINTER(_vp), _ci,
+                                       C.c_size_t, _ci, C.POINTER(_ci * 8), C.POINTER(_dbl)]),
 }
 
 
@@ -127,6 +129,7 @@ def _add_f32_signatures():
                 conv.append(a)
         SIGNATURES["armon_hip_" + name + "_f32"] = (res, conv)
     SIGNATURES["armon_hip_sweep_f32"] = SIGNATURES["armon_hip_sweep"]
+    SIGNATURES["armon_hip_tune_placement_f32"] = SIGNATURES["armon_hip_tune_placement"]
 
 
 _add_f32_signatures()

@@ -2,4 +2,5 @@
 #define ARMON_SWEEP_REAL double
 #define ARMON_SWEEP_FN armon_hip_sweep
 #define ARMON_SWEEP_DESC armon_sweep_desc
+#define ARMON_TUNE_FN armon_hip_tune_placement
 #include "fused_sweep_impl.hpp"

@@ -149,10 +149,11 @@ class BlockGrid:
         physical spacing, and for many spacings the 8 streams then keep meeting on the same channels/banks
         (tools/probes/probe_skew.hip, probe_pairs.hip: 2.93-3.77 ms for the same copy as a function of the
         spacing; random picks of 8 among 24 such vectors: 75 % at 2.71-2.79 ms, the back-to-back groups 2.94-3.08).
-        Nothing visible from user space predicts it, so it is measured: ``spare`` extra vectors are allocated,
-        ``placement_tries`` assignments of the 8 roles to vectors of the pool are timed with one X and one Y
-        sweep of the real state (the first one being the back-to-back assignment), the fastest is kept and
-        the unused vectors are freed. Called by ``init_test``; ~20 ms per try, outside any timed region.
+        Nothing visible from user space predicts it, so it is measured (natively: ``armon_hip_tune_placement``):
+        ``spare`` extra vectors are allocated, ``placement_tries`` assignments of the 8 roles to vectors of the pool
+        are timed with one X and one Y sweep of the real state (the first one being the back-to-back assignment),
+        the fastest is kept and the unused vectors are freed. Called by ``init_test``; ~20 ms per try, outside any
+        timed region.
         Returns the report also stored in ``self.placement``."""
         params, dev = self.params, self.params.device
         tries = getattr(params, "placement_tries", 0)
@@ -167,52 +168,33 @@ class BlockGrid:
         dt = 1e-3 * dx                    # any small step: the arithmetic does not depend on the data
         n, dt_ = self.data["rho"].n, self.data["rho"].dtype
         pool = [self.data[f] for f in STATE_VARS] + [self.alt[f] for f in STATE_VARS]
-        extra = []
         try:
-            for _ in range(spare + 4):
-                extra.append(dev.empty(n, dt_))
+            for _ in range(spare):
+                pool.append(dev.empty(n, dt_))
         except _lib.SolverException:          # not enough memory after all: keep the placement we have
-            for v in extra:
+            for v in pool[8:]:
                 v.free()
             return None
-        pool += extra[:spare]
-        master = dict(zip(STATE_VARS, extra[spare:]))           # the state is parked here while roles move around
-        for f in STATE_VARS:
-            master[f].copy_from_device(self.data[f])
-
-        def assign(pick):
-            for k, f in enumerate(STATE_VARS):
-                self.data[f], self.alt[f] = pool[pick[k]], pool[pick[4 + k]]
-                self.data[f].copy_from_device(master[f])
-
-        def timed():
-            best = math.inf
-            for rep in range(3):
-                dev.event_record(ARMON_EVENT_SCRATCH)
-                for axis in (Axis.X, Axis.Y):          # as in a cycle: X reads set A and writes set B, Y reads B, writes A
-                    d = sweep_desc(params, self, axis, dt, dx, emit_dt=axis == Axis.Y)
-                    check(params.fn("sweep")(dev.ctx, C.byref(d)))
-                    self.swap_state()
-                dev.event_record(ARMON_EVENT_SCRATCH + 1)
-                ms = dev.event_elapsed_ms(ARMON_EVENT_SCRATCH, ARMON_EVENT_SCRATCH + 1)
-                if rep:
-                    best = min(best, ms)
-            return best
-
-        rng = np.random.default_rng(12345)
-        picks = [list(range(8))] + [[int(i) for i in rng.permutation(len(pool))[:8]] for _ in range(tries - 1)]
-        times = []
-        for pick in picks:
-            assign(pick)
-            times.append(timed())
-        k = times.index(min(times))
-        assign(picks[k])
-        dev.wait()
-        keep = {id(pool[i]) for i in picks[k]}
-        for v in pool + list(master.values()):
-            if id(v) not in keep:
+        d_x = sweep_desc(params, self, Axis.X, dt, dx)
+        d_y = sweep_desc(params, self, Axis.Y, dt, params.cell_size(1), emit_dt=True)     # as in a cycle
+        ptrs = (C.c_void_p * len(pool))(*[v.ptr for v in pool])
+        picks, times = (C.c_int * 8)(), (C.c_double * tries)()
+        try:
+            check(params.fn("tune_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes, tries,
+                                              C.byref(picks), times))
+        except _lib.SolverException:          # e.g. no room for the 4 transient vectors: nothing was moved
+            for v in pool[8:]:
                 v.free()
-        self.placement = {"tries": len(picks), "pool": len(pool),
+            return None
+        picks, times = list(picks), list(times)
+        for k, f in enumerate(STATE_VARS):
+            self.data[f], self.alt[f] = pool[picks[k]], pool[picks[4 + k]]
+        keep = set(picks)
+        for i, v in enumerate(pool):
+            if i not in keep:
+                v.free()
+        k = times.index(min(times))
+        self.placement = {"tries": tries, "pool": len(pool),
                           "x_plus_y_ms": [round(t, 3) for t in times], "chosen": k}
         return self.placement
 

@@ -291,6 +291,20 @@ typedef struct {
 
 ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
 
+/* Placement of the 8 vectors a fused sweep streams (4 read + 4 written). On MI355X the same sweeps run 10-20 %
+ * apart depending on where these vectors sit in HBM relative to each other (back-to-back allocations end up at a
+ * regular physical spacing that makes the 8 streams collide on channels/banks), so a host
+ * should allocate a few spare vectors once and let this call choose: `pool` holds n_pool >= 8 device vectors of
+ * `bytes` bytes, pool[0..3] = the current (rho,u,v,E) WITH the state, pool[4..7] = their ping-pong partners, the
+ * rest spares. `tries` role assignments (the first = pool[0..7] as given, the others random) are timed with the
+ * caller's own descriptors as in a cycle — X reads roles 0..3 and writes 4..7, Y reads 4..7 and writes 0..3; all
+ * other fields of x_desc / y_desc are used as they are (dt_cfl_out included), their 8 state pointers are ignored.
+ * On return picks[role] = index in `pool` of the vector to use for that role, the state lives in pool[picks[0..3]],
+ * every other vector of the pool is free for the caller to release; times_ms (nullable, [tries]) = the best
+ * X+Y time of each assignment. Synchronous; needs 4 more vectors of `bytes` transiently. No reference counterpart. */
+ARMON_API int armon_hip_tune_placement(armon_ctx*, const armon_sweep_desc* x_desc, const armon_sweep_desc* y_desc,
+        void* const* pool, int n_pool, size_t bytes, int tries, int picks[8], double* times_ms);
+
 typedef struct {
     int32_t axis;            /* ARMON_AXIS_X / _Y                                               */
     int32_t scheme;          /* ARMON_SCHEME_*                                                  */
@@ -330,6 +344,8 @@ typedef struct {
 } armon_sweep_desc_f32;   /* same layout; scalars stay double and are rounded to float inside */
 
 ARMON_API int armon_hip_sweep_f32(armon_ctx*, const armon_sweep_desc_f32*);
+ARMON_API int armon_hip_tune_placement_f32(armon_ctx*, const armon_sweep_desc_f32* x_desc, const armon_sweep_desc_f32* y_desc,
+        void* const* pool, int n_pool, size_t bytes, int tries, int picks[8], double* times_ms);
 
 #ifdef __cplusplus
 }
