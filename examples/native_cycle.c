@@ -57,6 +57,34 @@ int main(int argc, char** argv)
     d.eos = ARMON_EOS_PERFECT_GAS; d.nghost = g; d.bc_low = d.bc_high = 1; d.nx = d.ny = n; d.dx = dx; d.gamma = 1.4;
     d.cfl_dx = d.cfl_dy = dx;
 
+    /* Placement of the 8 streamed vectors: 8 spare vectors, 12 role assignments timed by the
+     * library with these very descriptors; keep the 8 it picks, free the rest. */
+    if ((size_t)cells * sizeof(double) >= ((size_t)256 << 20)) {
+        void* pool[16] = {rho, u, v, E, rho2, u2, v2, E2};
+        int picks[8];
+        double times[12];
+        for (int k = 8; k < 16; k++) CHECK(armon_hip_malloc(ctx, (size_t)cells * sizeof(double), &pool[k]));
+        armon_sweep_desc tx = d, ty = d;
+        tx.axis = ARMON_AXIS_X; ty.axis = ARMON_AXIS_Y; tx.dt = ty.dt = 1e-3 * dx;
+        tx.u_factor_low = tx.u_factor_high = -1.; tx.v_factor_low = tx.v_factor_high = 1.;
+        ty.u_factor_low = ty.u_factor_high = ty.v_factor_low = ty.v_factor_high = 1.;
+        ty.dt_cfl_out = dt_dev;
+        CHECK(armon_hip_tune_placement(ctx, &tx, &ty, pool, 16, (size_t)cells * sizeof(double), 12, picks, times));
+        double* chosen[8];
+        for (int k = 0; k < 8; k++) chosen[k] = (double*)pool[picks[k]];
+        for (int k = 0; k < 16; k++) {
+            int kept = 0;
+            for (int j = 0; j < 8; j++) kept |= picks[j] == k;
+            if (!kept) CHECK(armon_hip_free(ctx, pool[k]));
+        }
+        rho = chosen[0]; u = chosen[1]; v = chosen[2]; E = chosen[3];
+        rho2 = chosen[4]; u2 = chosen[5]; v2 = chosen[6]; E2 = chosen[7];
+        f[2] = rho; f[3] = u; f[4] = v; f[5] = E; f[16] = rho2; f[17] = u2; f[18] = v2; f[19] = E2;
+        printf("placement: X+Y ms per try:");
+        for (int k = 0; k < 12; k++) printf(" %.2f", times[k]);
+        printf("\n");
+    }
+
     CHECK(armon_hip_sync(ctx));
     const double t0 = now();
     for (int c = 0; c < cycles; c++) {
