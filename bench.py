@@ -241,7 +241,7 @@ def main():
                    "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local,
-                   "hbm_placement": grid.placement},
+                   "hbm_placement": grid.placement, "device": params.device.name},
         "hbm_GBps_algorithmic_whole_job": round((32 if args.f32 else 64) * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,
     }
