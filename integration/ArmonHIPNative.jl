@@ -1,15 +1,11 @@
-# INTEGRATION — binding `libarmon_hip.so` into Armon.jl
-
-`libarmon_hip.so` (built by `python armon.jl_amd/build.py`, declared in `include/armon_hip.h`) is a plain C ABI:
-device pointers, `Int64`/`Float64`/`Cint` scalars, one 40-byte range struct. Armon.jl would bind it exactly the way
-it binds its Kokkos kernel library (`ext/ArmonKokkos.jl`): a package extension that defines a device type and adds
-more specific methods of the open generic functions listed in SURVEY.md §8(b). `julia` is not available in the build
-image, so the file below is written against the reference's sources and has not been executed; the same ABI is
-exercised end to end by the Python host (`armon.jl_amd/_lib.py`, `tests/`).
-
-## 1. Extension skeleton (`ext/ArmonHIPNative.jl`; complete file: `integration/ArmonHIPNative.jl`)
-
-```julia
+# ArmonHIPNative.jl — package extension binding libarmon_hip.so into Armon.jl (Keluaa/Armon.jl @ 2024_08_07).
+#
+# NOT EXECUTED in the build image (no `julia` there): written against the reference's sources, following its own
+# Kokkos extension (ext/ArmonKokkos.jl). The ABI it binds is exercised end to end by the Python host
+# (armon.jl_amd/_lib.py, tests/) and by examples/native_cycle.c. See INTEGRATION.md for the walk-through.
+#
+# Install: copy to Armon.jl/ext/, declare it in Project.toml ([extensions] ArmonHIPNative = ...), then
+#   ArmonParameters(; use_gpu=true, device=:HIP_native, use_cache_blocking=false, armon_hip_lib="/path/libarmon_hip.so", ...)
 module ArmonHIPNative
 
 using Armon
@@ -119,7 +115,11 @@ function pack_to_array!(p::HP, r::DomainRange, bsize, side, array, vars::NTuple{
     check(ccall((:armon_hip_pack_to_array, lib[]), Cint, (Ptr{Cvoid}, CRange, Cint, Int64, P, Cint, Ptr{P}),
         p.device.ctx, CRange(r), ghosts(bsize), real_face_size(bsize, side), array, N, ptrs))
 end
-# unpack_from_array!: identical with :armon_hip_unpack_from_array
+function unpack_from_array!(p::HP, r::DomainRange, bsize, side, array, vars::NTuple{N}; kw...) where N
+    ptrs = [Base.unsafe_convert(P, v) for v in vars]
+    check(ccall((:armon_hip_unpack_from_array, lib[]), Cint, (Ptr{Cvoid}, CRange, Cint, Int64, P, Cint, Ptr{P}),
+        p.device.ctx, CRange(r), ghosts(bsize), real_face_size(bsize, side), array, N, ptrs))
+end
 
 function dtCFL_kernel(p::HP, state::SolverState, blk::LocalTaskBlock, Δx::NTuple{2})   # ref src/reductions.jl:65
     d = block_device_data(blk); r = block_domain_range(blk.size, state.steps_ranges.real_domain); out = Ref{Float64}()
@@ -135,28 +135,24 @@ function conservation_vars(p::HP, blk::LocalTaskBlock)                          
         p.device.ctx, CRange(r), ds, d.ρ, d.E, out))
     out[]
 end
-# init_test: :armon_hip_init_test with the test tag of ext/ArmonKokkos.jl:60-69 and a 16-pointer struct
-# mirroring BlockData's field order (x,y,ρ,u,v,E,p,c,g,uˢ,pˢ,work_1..4,mask).
+# init_test (ref src/kernels.jl:106-145,176-207): test tag as in ext/ArmonKokkos.jl:60-69, the 16 BlockData vectors
+# in field order (== armon_block_data), the block's global position and the cell sizes. The library zeroes uˢ,pˢ,work_*.
+struct CBlockData; x::P; y::P; ρ::P; u::P; v::P; E::P; p::P; c::P; g::P; uˢ::P; pˢ::P; w1::P; w2::P; w3::P; w4::P; mask::P; end
+test_tag(::Armon.Sod) = Cint(0); test_tag(::Armon.Sod_y) = Cint(1); test_tag(::Armon.Sod_circ) = Cint(2)
+test_tag(::Armon.Bizarrium) = Cint(3); test_tag(::Armon.Sedov) = Cint(4); test_tag(::Armon.DebugIndexes) = Cint(5)
+function init_test(p::HP, d::BlockData, r::DomainRange, global_pos, bsize, ΔX, vars_to_zero, test; kw...)
+    bd = Ref(CBlockData(d.x, d.y, d.ρ, d.u, d.v, d.E, d.p, d.c, d.g, d.uˢ, d.pˢ, d.work_1, d.work_2, d.work_3, d.work_4, d.mask))
+    gpos = Ref(NTuple{2,Int64}(global_pos)); gN = Ref(NTuple{2,Int64}(p.global_grid))
+    origin = Ref(NTuple{2,Float64}(p.origin)); dX = Ref(NTuple{2,Float64}(ΔX))
+    sz = Armon.block_size(bsize)
+    check(ccall((:armon_hip_init_test, lib[]), Cint,
+        (Ptr{Cvoid}, CRange, Cint, Int64, Int64, Cint, Ptr{NTuple{2,Int64}}, Ptr{NTuple{2,Int64}}, Ptr{NTuple{2,Float64}},
+         Ptr{NTuple{2,Float64}}, Float64, Ptr{CBlockData}),
+        p.device.ctx, CRange(r), test_tag(test), sz[1], sz[2], ghosts(bsize), gpos, gN, origin, dX,
+        test isa Armon.Sedov ? test.r : 0.0, bd))
+end
 
-end # module
-```
-
-`data_type=Float32` binds the same symbols with an `_f32` suffix (`armon_hip_acoustic_GAD_f32`, …,
-`armon_hip_sweep_f32`): `Float32` arrays and scalars, identical argument order; the methods above become
-`ArmonParameters{T, HIPNative}` methods that pick the symbol from `T`.
-
-Select it with `ArmonParameters(; use_gpu=true, device=:HIP_native, use_cache_blocking=false, ...)`
-(`src/parameters.jl:392-405`). All calls are asynchronous on the context's stream; `wait(params)` is the only
-synchronisation, exactly where the reference already places it (`src/solver.jl:381`, `src/halo_exchange.jl:244`,
-`src/io.jl:188-190`).
-
-## 2. Using the fused sweep from Julia
-
-The staged overrides above make the backend a drop-in with the reference's five passes per sweep. To get the fused
-kernel, override the sweep body of `solver_cycle` for this device instead (precedent: `ext/ArmonKokkos.jl:212-258`
-overrides whole reductions on its device type):
-
-```julia
+# ---- fused sweep + placement of the streamed vectors (INTEGRATION.md §2) -------------------------------------
 Base.@kwdef struct SweepDesc      # == armon_sweep_desc, include/armon_hip.h
     axis::Cint; scheme::Cint; limiter::Cint; projection::Cint; eos::Cint; nghost::Cint
     bc_low::Cint; bc_high::Cint; exact::Cint = 0; x_kernel::Cint = 0
@@ -164,48 +160,18 @@ Base.@kwdef struct SweepDesc      # == armon_sweep_desc, include/armon_hip.h
     u_factor_low::Float64; v_factor_low::Float64; u_factor_high::Float64; v_factor_high::Float64
     rho_in::P; u_in::P; v_in::P; E_in::P; rho_out::P; u_out::P; v_out::P; E_out::P
     p_out::P = C_NULL; c_out::P = C_NULL; dt_cfl_out::P = C_NULL; cfl_dx::Float64 = 0; cfl_dy::Float64 = 0
-    out_lo::Int64 = 0; out_hi::Int64 = 0          # partial sweep [out_lo, out_hi) (0 = whole block): halo overlap
-    dt_accumulate::Cint = 0; reserved::Cint = 0
+    out_lo::Int64 = 0; out_hi::Int64 = 0; dt_accumulate::Cint = 0; reserved::Cint = 0
 end
 fused_sweep!(p::HP, desc::SweepDesc) =
     check(ccall((:armon_hip_sweep, lib[]), Cint, (Ptr{Cvoid}, Ref{SweepDesc}), p.device.ctx, desc))
-```
 
-with a second set of four state vectors per block (ping-pong) swapped after each sweep — what
-`armon.jl_amd/solver.py: fused_sweep / solver_cycle` does. `dt_cfl_out` gives the next cycle's `local_time_step`
-(`src/reductions.jl:97-110`) without a separate pass; `p_out` materialises the `p` that `saved_vars`
-(`src/blocking/blocks.jl:49`) expects after the last sweep.
+"pool[1:4] = (ρ,u,v,E) holding the state, pool[5:8] their ping-pong partners, the rest spares → indices to keep"
+function tune_placement!(p::HP, x_desc::SweepDesc, y_desc::SweepDesc, pool::Vector{<:HIPVector}; tries = 12)
+    ptrs = [Ptr{Cvoid}(v.ptr) for v in pool]; picks = zeros(Cint, 8); times = zeros(Float64, tries)
+    check(ccall((:armon_hip_tune_placement, lib[]), Cint,
+        (Ptr{Cvoid}, Ref{SweepDesc}, Ref{SweepDesc}, Ptr{Ptr{Cvoid}}, Cint, Csize_t, Cint, Ptr{Cint}, Ptr{Float64}),
+        p.device.ctx, x_desc, y_desc, ptrs, length(pool), sizeof(eltype(pool[1])) * pool[1].n, tries, picks, times))
+    picks .+ 1, times
+end
 
-Two things the Python host does around that call and a Julia host should do too:
-
-* **MPI runs**: hand the library the stream the communication library orders itself on
-  (`armon_hip_init(device_id, stream, ctx)` with AMDGPU.jl's stream) so that pack → send and recv → unpack need no
-  host synchronisation, and sweep the interior `[LAG, n-LAG)` between `start_exchange` and `finish_exchange`
-  (`out_lo/out_hi`), then the two LAG-wide strips with `dt_accumulate = 1` — `solver.py: fused_sweep_overlapped`.
-* **Placement of the state vectors**: the four `*_in` and four `*_out` vectors of a block should not come from
-  back-to-back allocations (DESIGN §3: 10–20 % of HBM bandwidth depends on their relative physical placement).
-  Allocate 8 spare vectors once and call `armon_hip_tune_placement(ctx, x_desc, y_desc, pool, n_pool, bytes, tries,
-  picks, times_ms)`: it times `tries` role assignments with the caller's own X and Y sweeps, leaves the state in
-  `pool[picks[0..3]]` and tells which 8 vectors to keep (`solver.py: BlockGrid.tune_placement` is the Python caller;
-  from Julia it is one `ccall` after `init_test`).
-
-## 3. Python / ctypes binding (what the tests run)
-
-```python
-import ctypes as C
-L = C.CDLL("armon.jl_amd/libarmon_hip.so")
-ctx = C.c_void_p(); assert L.armon_hip_init(0, None, C.byref(ctx)) == 0
-# ... see armon.jl_amd/_lib.py: SIGNATURES lists every symbol of include/armon_hip.h with its argtypes
-```
-
-`import armon_amd; armon_amd.armon(armon_amd.ArmonParameters(test="Sod", N=(100, 100)))` runs the reference's
-`armon(ArmonParameters(; test=:Sod, N=(100,100), ...))` on the GPU.
-
-## 4. Plain C
-
-`examples/native_cycle.c` drives the same hot path from C99 through `include/armon_hip.h` alone — allocation,
-`init_test`, `armon_hip_tune_placement`, X/Y fused sweeps with the fused dt reduction, the reference's dt rule with the asynchronous read-back
-(`armon_hip_memcpy_async` + `armon_hip_event_record/_sync`), conservation sums. `tests/test_native_example.py` checks
-that the header is valid C99 and C++11, that the example builds, and (on a GPU) that it ends on the same mass and
-energy, bit for bit, as the Python host after the same number of cycles. On one MI355X:
-`examples/native_cycle 16384 50` → 5.70 ms per cycle, 94.2 Gcells/s per sweep.
+end # module
