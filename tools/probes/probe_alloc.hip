@@ -31,7 +31,15 @@ int main(int argc, char** argv)
         for (int k = 0; k < 8; k++) a[k] = slab + k * S;
     } else {
         if (mode == 'D') { char* slab; CK(hipMalloc(&slab, 8 * 2060 * MiB)); CK(hipMemset(slab, 0, 8 * 2060 * MiB)); CK(hipDeviceSynchronize()); CK(hipFree(slab)); }
-        for (int k = 0; k < 8; k++) CK(hipMalloc(&a[k], mode == 'B' ? 4096 * MiB : bytes + pad * 2 * MiB));
+        // F: irregular paddings (triangular numbers x pad x 2 MiB), G: pseudo-random paddings below pad x 64 MiB
+        static const size_t tri[8] = {0, 1, 3, 6, 10, 15, 21, 28};
+        unsigned long long rng = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < 8; k++) {
+            size_t extra = pad * 2 * MiB;
+            if (mode == 'F') extra = tri[k] * pad * 2 * MiB;
+            if (mode == 'G') { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; extra = (rng % (pad * 32)) * 2 * MiB; }
+            CK(hipMalloc(&a[k], mode == 'B' ? 4096 * MiB : bytes + extra));
+        }
     }
     for (int k = 0; k < 8; k++) CK(hipMemset(a[k], 0, bytes));
     ptrs p;
