@@ -9,7 +9,10 @@ initial conditions (init_test) already resident in HBM. Prints ONE JSON line on 
 
  value      = Mcells/s per sweep = cells(all ranks) · 2 sweeps · K / time / 1e6       
  roofline   = dominant kernel (the fused sweep, or euler_projection in --staged mode) timed live with
-              HIP events on the kernel's stream; achieved = algorithmic B/cell · cells / mean duration
+              HIP events on the kernel's stream; achieved = algorithmic B/cell · cells / mean duration per
+              sweep; plus stream_copy_GBps_this_device / frac_of_stream_copy: the same bytes as a plain
+              4-in/4-out copy on the same device and vectors, measured right after the timed region
+ config.hbm_placement = the draws of BlockGrid.tune_placement (done at init_test, before any timing)
  cpu_baseline = the CPU oracle ("port": OpenMP restatement of the reference's 5-pass CPU path) timed on
               this host's cores on a bounded sample (rank 0, N=1 only)
 """
