@@ -18,14 +18,30 @@ pytestmark = pytest.mark.gpu
     ((1, 2), (48, 33), "Sod_y", dict(maxcycle=8, axis_splitting="Strang")),
 ])
 def test_two_tiles_equal_one_block(tmp_path, P, N, test, opts, fused):
+    check_tiles(tmp_path, P, N, test, opts, fused)
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["staged", "fused"])
+@pytest.mark.parametrize("P,N,test,opts", [
+    ((3, 1), (70, 24), "Sod_circ", dict(maxcycle=10)),                  # middle tile: remote on BOTH sides of x (as px = 4)
+    ((1, 3), (24, 70), "Sod_circ", dict(maxcycle=10)),
+    ((2, 2), (48, 40), "Sod_circ", dict(maxcycle=10)),                  # remote sides on both axes
+    ((2, 2), (45, 37), "Sedov", dict(maxcycle=10, axis_splitting="Godunov")),
+])
+def test_more_tiles_equal_one_block(tmp_path, P, N, test, opts, fused):
+    check_tiles(tmp_path, P, N, test, opts, fused)
+
+
+def check_tiles(tmp_path, P, N, test, opts, fused):
     import armon_amd
+    world = P[0] * P[1]
     o = dict(opts, use_fused_sweep=fused, exact_arithmetic=True)
-    spawn(dist_workers.gpu_solver_worker, 2, P, N, test, o, str(tmp_path))
+    spawn(dist_workers.gpu_solver_worker, world, P, N, test, o, str(tmp_path))
     params = armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True, **o)
     ref = armon_amd.armon(params)
     host = ref.data.device_to_host(("rho", "u", "v", "E", "p"))
     full = {k: ref.data.real_view(v) for k, v in host.items()}
-    for r in range(2):
+    for r in range(world):
         t = np.load(tmp_path / f"tile{r}.npz")
         assert int(t["cycles"]) == ref.cycles and float(t["dt"]) == ref.last_dt and float(t["time"]) == ref.final_time
         ox, oy = (int(v) - 1 for v in t["origin"])
