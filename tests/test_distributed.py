@@ -33,6 +33,16 @@ def test_halo_exchange_with_index_encoded_data(tmp_path, P, N):
     assert sizes[0][d] == n0 and sizes[1][d] == N[d] - n0 and sizes[0][1 - d] == N[1 - d]
 
 
+@pytest.mark.parametrize("P,N", [((3, 1), (40, 12)), ((1, 3), (12, 40)), ((2, 2), (24, 20)), ((4, 1), (50, 9))])
+def test_halo_exchange_more_ranks(tmp_path, P, N):
+    """Middle tiles talk to two peers along an axis (as with px = 4 on 8 GPUs); 2×2 tiles have remote sides on both axes."""
+    world = P[0] * P[1]
+    spawn(dist_workers.halo_index_worker, world, P, N, str(tmp_path))
+    for r in range(world):
+        lines = open(tmp_path / f"rank{r}.txt").read().splitlines()
+        assert lines[0] == "OK", lines
+
+
 def test_split_too_small_for_ghosts_is_rejected():
     """ref src/parameters.jl:684-690"""
     import armon_amd
