@@ -484,7 +484,9 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     const int64_t row_off = (row + a.g) * a.row_len + a.g;
     const real* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
     real* out[4] = {a.rho_out + row_off, a.ua_out + row_off, a.ut_out + row_off, a.E_out + row_off};
-    const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && (a.g % 2 == 0) && (a.o_lo % 2 == 0);   // uniform
+    // 16-B accesses need every lane pair on an even cell of an even-pitched row; strip origins are multiples of 8 cells
+    // from the row start (x_first), so an odd o_lo (partial sweeps with LAG = 3) only masks half of one pair
+    const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && ((a.x_first + a.g) % 2 == 0);   // uniform
 
     SW sw{a.dt, a.dx, a.gamma};
     cfl_track cfl;

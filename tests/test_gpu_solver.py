@@ -244,7 +244,7 @@ def test_alternative_x_kernels(oracle, test, N, opts, xk, exact):
 
 @pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
 @pytest.mark.parametrize("axis_name", ["X", "Y"])
-@pytest.mark.parametrize("scheme,projection", [("GAD", "euler_2nd"), ("Godunov", "euler")])
+@pytest.mark.parametrize("scheme,projection", [("GAD", "euler_2nd"), ("Godunov", "euler"), ("GAD", "euler")])
 def test_partial_sweeps_equal_the_full_sweep(axis_name, scheme, projection, exact):
     """interior [LAG, n-LAG) + the two LAG-wide strips == one full sweep, including the fused dt."""
     import armon_amd
