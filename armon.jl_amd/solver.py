@@ -22,7 +22,6 @@ MAIN_VARS = ("x", "y", "rho", "u", "v", "E", "p", "c", "g", "us", "ps")   # ref 
 SAVED_VARS = ("x", "y", "rho", "u", "v", "p")                              # ref :49
 COMM_VARS = ("rho", "u", "v", "E", "p", "c", "g")                          # ref :50
 STATE_VARS = ("rho", "u", "v", "E")
-ARMON_EVENT_SCRATCH = 1010        # event-pool slots used by BlockGrid.tune_placement
 
 
 @dataclass
