@@ -246,8 +246,8 @@ def _range(params, corners):
     return params.block_size.domain_range(*corners).to_c()
 
 
-def init_test(params, grid):
-    """ref src/kernels.jl:176-207"""
+def init_test(params, grid, tune=True):
+    """ref src/kernels.jl:176-207 (+ the measured choice of the HBM placement, ``tune=False`` to skip it)"""
     bs = params.block_size
     full = params.steps_ranges[Axis.X].full_domain
     gpos = (C.c_int64 * 2)(params.N_origin[0] - 1, params.N_origin[1] - 1)
@@ -259,7 +259,8 @@ def init_test(params, grid):
     check(params.fn("init_test")(params.device.ctx, _range(params, full), params.test.tag,
                                    bs.size[0], bs.size[1], bs.ghosts, C.byref(gpos), C.byref(gN),
                                    C.byref(origin), C.byref(dX), params.test.r, C.byref(bd)))
-    grid.tune_placement()
+    if tune:
+        grid.tune_placement()
 
 
 def update_EOS(params, grid, axis=Axis.X):

@@ -160,6 +160,42 @@ def main():
     gdt = grid.global_dt
     gdt.reset()
 
+    # N > 1 over RCCL: the stream-ordered halo exchange (no host synchronisation) is checked on THIS machine against
+    # the host-synchronised protocol before anything is timed: a few cycles in each mode from the same initial state
+    # must give the same dt sequence and the same global mass / energy, bit for bit; if not, the timed run uses
+    # the host-synchronised protocol and says so.
+    halo_mode = None
+    if dist is not None and grid.comm is not None:
+        halo_mode = "stream-ordered" if grid.comm.stream_ordered else "host-synchronised"
+        if grid.comm.stream_ordered:
+            from armon_amd.solver import conservation_vars, drain_halo
+
+            def probe(stream_ordered, cycles=5):
+                grid.comm.stream_ordered = stream_ordered
+                init_test(params, grid, tune=False)
+                gdt.reset()
+                grid.dt_inflight.clear()
+                dts = []
+                for _ in range(cycles):
+                    solver_cycle(params, grid, last_cycle=False)
+                    dts.append(float(gdt.current_dt))
+                    gdt.next_cycle()
+                drain_halo(grid)
+                params.wait()
+                return dts, conservation_vars(params, grid)
+
+            ref = probe(False)
+            got = probe(True)
+            same = 1.0 if ref == got else 0.0
+            from armon_amd.halo_exchange import allreduce_min
+            same = allreduce_min(params, same)
+            grid.comm.stream_ordered = same == 1.0
+            halo_mode = ("stream-ordered (self-check against the host-synchronised protocol passed)" if same == 1.0
+                         else "host-synchronised (the stream-ordered self-check FAILED on this machine)")
+            init_test(params, grid, tune=False)
+            gdt.reset()
+            grid.dt_inflight.clear()
+
     dominant = ("sweep_x", "sweep_y") if not args.staged else ("euler_projection",)
     timer = EventTimer(params.device, dominant)
     params.kernel_callbacks.append(timer)
@@ -244,7 +280,7 @@ def main():
                    "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local,
-                   "hbm_placement": grid.placement, "device": params.device.name},
+                   "hbm_placement": grid.placement, "device": params.device.name, "halo_exchange": halo_mode},
         "hbm_GBps_algorithmic_whole_job": round((32 if args.f32 else 64) * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,
     }
