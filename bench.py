@@ -196,6 +196,9 @@ def main():
             gdt.reset()
             grid.dt_inflight.clear()
 
+    from armon_amd.solver import conservation_vars
+    mass0, energy0 = conservation_vars(params, grid)         # self-check of the timed work, see below
+
     dominant = ("sweep_x", "sweep_y") if not args.staged else ("euler_projection",)
     timer = EventTimer(params.device, dominant)
     params.kernel_callbacks.append(timer)
@@ -230,6 +233,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # Self-check that the timed cycles did the work: global mass and energy against the initial state, and (for the
+    # test cases that vary along one axis only) every row / column of this rank's density identical and finite.
+    import numpy as np
+    mass1, energy1 = conservation_vars(params, grid)
+    self_check = {"mass_drift": abs(mass1 - mass0) / abs(mass0), "energy_drift": abs(energy1 - energy0) / abs(energy0)}
+    if rank == 0 and args.test in ("Sod", "Sod_y", "Bizarrium"):
+        rho = grid.real_view(grid.data["rho"].to_host())
+        line = rho[:, 0:1] if args.test == "Sod_y" else rho[0:1]
+        self_check["lines_identical"] = bool(np.isfinite(rho).all() and np.array_equal(rho, np.broadcast_to(line, rho.shape)))
+        self_check["moved"] = bool(np.unique(line).size > 2)          # the waves have left the initial two states
+        del rho
 
     # Practical ceiling on THIS device: the same bytes (4 arrays read + 4 written) as a plain copy, no arithmetic.
     copy_gbps = None
@@ -283,6 +298,7 @@ def main():
                    "hbm_placement": grid.placement, "device": params.device.name, "halo_exchange": halo_mode},
         "hbm_GBps_algorithmic_whole_job": round((32 if args.f32 else 64) * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,
+        "self_check": self_check,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.f32:
         try:
