@@ -450,7 +450,10 @@ k_sweep_y2(sweep_args a)
 // ---- X sweep, spatial form (lanes along x, DPP neighbour exchange) -------------------------------------
 // blockDim = (64, kXSRows): one wave per row, kXSRows consecutive rows per workgroup. Each wave walks
 // NITER strips of 64*K cells along its row; a strip yields 64*K - 2*HALO new cells.
-constexpr int kXSRows = 4;
+#ifndef ARMON_XS_ROWS
+#define ARMON_XS_ROWS 4          // rows (= waves) per workgroup of the X sweep (tuning macro)
+#endif
+constexpr int kXSRows = ARMON_XS_ROWS;
 constexpr int kXSNiter = 2;      // strips per wave (A/B over 1..137 with tools/ab_sweep.py: short-lived waves keep the global access order sequential)
 
 constexpr int kXSlots = 4096;    // dt/CFL tracking of the X sweep: slots the waves fold their maxima into
