@@ -58,6 +58,14 @@ class SweepDesc(C.Structure):
                 ("out_lo", C.c_int64), ("out_hi", C.c_int64), ("dt_accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
+class HaloDesc(C.Structure):
+    """armon_halo_desc — what one local tile exchanges (include/armon_hip.h)."""
+    _fields_ = [("nx", C.c_int64), ("ny", C.c_int64), ("nghost", C.c_int32), ("nvars", C.c_int32),
+                ("vars", C.c_void_p * 8)]
+
+
+MGPU_ID_BYTES = 256
+
 _lib = None
 
 # name → (restype, argtypes); every symbol include/armon_hip.h declares
@@ -107,6 +115,19 @@ SIGNATURES = {
     "armon_hip_sweep": (_ci, [_vp, C.POINTER(SweepDesc)]),
     "armon_hip_tune_placement": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc), C.POINTER(_vp), _ci,
                                        C.c_size_t, _ci, C.POINTER(_ci * 8), C.POINTER(_dbl)]),
+    "armon_hip_mgpu_init": (_ci, [_ci, _ci, C.POINTER(_ci), C.POINTER(_vp)]),
+    "armon_hip_mgpu_unique_id": (_ci, [_vp]),
+    "armon_hip_mgpu_init_rank": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, C.POINTER(_vp)]),
+    "armon_hip_mgpu_destroy": (_ci, [_vp]),
+    "armon_hip_mgpu_n_local": (_ci, [_vp]),
+    "armon_hip_mgpu_ctx": (_vp, [_vp, _ci]),
+    "armon_hip_mgpu_tile_info": (_ci, [_vp, _ci, C.POINTER(_ci), C.POINTER(_ci * 2), C.POINTER(_ci * 4)]),
+    "armon_hip_halo_exchange_start": (_ci, [_vp, _ci, C.POINTER(HaloDesc)]),
+    "armon_hip_halo_exchange_finish": (_ci, [_vp, _ci, C.POINTER(HaloDesc)]),
+    "armon_hip_halo_exchange": (_ci, [_vp, _ci, C.POINTER(HaloDesc)]),
+    "armon_hip_dt_allreduce": (_ci, [_vp, C.POINTER(_vp)]),
+    "armon_hip_mgpu_allreduce_host": (_ci, [_vp, _ci, _ci, C.POINTER(_dbl)]),
+    "armon_hip_halo_ranges": (_ci, [_i64, _i64, _ci, _ci, C.POINTER(Range), C.POINTER(Range), C.POINTER(_i64)]),
 }
 
 
@@ -128,6 +149,8 @@ def _add_f32_signatures():
             else:
                 conv.append(a)
         SIGNATURES["armon_hip_" + name + "_f32"] = (res, conv)
+    for name in ("halo_exchange_start", "halo_exchange_finish", "halo_exchange", "dt_allreduce"):
+        SIGNATURES["armon_hip_" + name + "_f32"] = SIGNATURES["armon_hip_" + name]
     SIGNATURES["armon_hip_sweep_f32"] = SIGNATURES["armon_hip_sweep"]
     SIGNATURES["armon_hip_tune_placement_f32"] = SIGNATURES["armon_hip_tune_placement"]
 

@@ -24,6 +24,7 @@
 #include "sweep_pipeline.hpp"
 #include "sweep_spatial.hpp"
 
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -195,7 +196,10 @@ k_fold_dt(const real* __restrict__ partials, int64_t n_blocks, real dx, real dy,
 }
 
 // ---- Y sweep ---------------------------------------------------------------------------------------
-constexpr int kYBlock = 256;
+#ifndef ARMON_Y_BLOCK
+#define ARMON_Y_BLOCK 256        // columns (= lanes) per workgroup of the Y march (tuning macro)
+#endif
+constexpr int kYBlock = ARMON_Y_BLOCK;
 #ifndef ARMON_Y_PF
 #define ARMON_Y_PF 4             // rows prefetched ahead of the march (≤ 5: the cell ring has 8 slots)
 #endif
@@ -301,8 +305,12 @@ k_sweep_y(sweep_args a)
         so_off += pitchb;
     };
     auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 8
-        for (int t = t0; t < t1; t += 8)
+        for (int t = t0; t < t1; t += 8) {
+#ifdef ARMON_Y_SYNC   // experiment: keep the waves of a workgroup on the same rows
+            if ((t & (ARMON_Y_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
+#endif
             static_for(std::make_integer_sequence<int, 8>{}, [&](auto ph) { step(ph, checked, jb + t + decltype(ph)::value); });
+        }
     };
 
     const int T = je - jb;                                   // steps of the run
@@ -313,10 +321,19 @@ k_sweep_y(sweep_args a)
     int M = (T < plain_end ? T : plain_end) & ~7;
     if (M < P || (a.emit & 3)) M = P;                        // p/c output: everything through the checked form
 
-    static_for(std::make_integer_sequence<int, PF>{}, [&](auto k) { load(k, std::true_type{}); });
-    run(std::true_type{}, 0, P < T8 ? P : T8);
-    run(std::false_type{}, P, M);
-    run(std::true_type{}, M, T8);
+    // The block origin shift leaves the last workgroup of a row mostly past the last column: a wave with no
+    // column at all skips the march (it still joins the block reduction below with neutral values).
+#ifdef ARMON_Y_SYNC
+    const bool wave_idle = false;
+#else
+    const bool wave_idle = (int)(blockIdx.x * kYBlock + (threadIdx.x & ~63u)) - a.xshift >= nx;   // wave-uniform
+#endif
+    if (!wave_idle) {
+        static_for(std::make_integer_sequence<int, PF>{}, [&](auto k) { load(k, std::true_type{}); });
+        run(std::true_type{}, 0, P < T8 ? P : T8);
+        run(std::false_type{}, P, M);
+        run(std::true_type{}, M, T8);
+    }
 
     if (TRACK) cfl_block_store<kYBlock / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
@@ -732,6 +749,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
         return check_launch("sweep_y");
     }
+#ifndef ARMON_ONLY_HEADLINE
     if (a.x_kernel == 2) {
         dim3 grid((unsigned)((n_out + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
         *n_blocks = (int64_t)grid.x * grid.y;
@@ -739,6 +757,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         hipLaunchKernelGGL((k_sweep_x_lds<PIPE, kXChunk, TRACK>), grid, dim3(kXRows), lds, ctx->stream, a);
         return check_launch("sweep_x_lds");
     }
+#endif
     const char* niter_s = getenv("ARMON_XS_NITER");                  // tuning knob, read per launch (A/B runs)
     const int niter_env = niter_s ? atoi(niter_s) : 0;
     const int niter = niter_env > 0 ? niter_env : kXSNiter;
@@ -752,30 +771,41 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
             return check_launch("sweep_x_dpp (slots)");
         *n_blocks = kXSlots;
     }
+#ifndef ARMON_ONLY_HEADLINE
     if (k1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
                            grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
     else
+#endif
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK>),
                            grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
     return check_launch("sweep_x_dpp");
 }
 
-// Rows per run of the Y march. A run re-reads 2·LAG halo rows, so long runs are cheaper per cell, but the grid
-// must still fill the device evenly: at 2 waves/SIMD the chip holds n_cu·8 waves, and a grid of 1.06 such rounds
-// takes 2. Pick the length that minimises rounds × (rows + halo) (A/B on 4096²: 32 rows -16 % against 128; 8192²:
-// 64 rows -4 %; 16384²: 128).
-int y_run_length(int n_cu, int64_t nx, int64_t ny)
+// Rows per run of the Y march. A run re-reads 2·LAG halo rows (and recomputes them), so long runs are cheaper per
+// cell, but the launch must still fill the device evenly: the chip holds n_cu·ARMON_Y_WAVES·4 waves of this kernel
+// at once and a launch of 4.06 such rounds takes nearly 5. Choose the number of runs per column that minimises
+// rounds × (rows + halo), the rounds counted half-way between the exact ratio and its ceiling (waves drift apart,
+// so a partial last round costs less than a whole one), among the launches of at least two rounds (a single round
+// of long-lived workgroups exposes the whole ramp-up and tail: 4096², 137 rows in one round is 5 % slower than 32
+// rows in 4.25). Measured at 16384² (tools/y_ab_r02.sh, one process): 128 rows 3.17 ms, 256: 3.12, 421: 3.09,
+// 529: 3.08, 713: 3.09, 1093: 3.12, 2341 (one round, 11 % of the slots empty): 3.19.
+int y_run_length(int n_cu, int64_t nx, int64_t ny, int lag)
 {
-    const int64_t slots = (int64_t)n_cu * 8, cols = (nx + 16 + kYBlock - 1) / kYBlock;
-    int best = 128;
+    const double slots = (double)n_cu * ARMON_Y_WAVES * 4 / (kYBlock / 64);         // workgroups resident at once
+    const int64_t cols = (nx + 16 + kYBlock - 1) / kYBlock;
+    int best = (int)(ny < 32 ? ny : 32);
     double best_cost = 1e300;
-    for (int seg : {128, 96, 64, 32}) {
-        const int64_t waves = cols * ((ny + seg - 1) / seg) * (kYBlock / 64);
-        const double cost = (double)((waves + slots - 1) / slots) * (seg + 8);
-        if (cost < best_cost * 0.97) {       // prefer the longer run unless the shorter one clearly wins
+    for (int64_t nruns = 1; nruns <= ny; nruns++) {
+        const int64_t seg = (ny + nruns - 1) / nruns;
+        if (seg < 32) break;
+        if ((ny + seg - 1) / seg != nruns) continue;                              // same launch as a smaller nruns
+        const double rounds = (double)(cols * nruns) / slots;
+        if (rounds < 2.) continue;
+        const double cost = 0.5 * (rounds + std::ceil(rounds)) * (double)(seg + 2 * lag);
+        if (cost < best_cost) {
             best_cost = cost;
-            best = seg;
+            best = (int)seg;
         }
     }
     return best;
@@ -835,9 +865,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     ARMON_REQUIRE(d->scheme != ARMON_SCHEME_GAD || (d->limiter >= ARMON_LIMITER_NONE && d->limiter <= ARMON_LIMITER_SUPERBEE),
                   "unknown limiter tag %d", d->limiter);
     ARMON_REQUIRE(d->nx > 0 && d->ny > 0, "empty block %lld x %lld", (long long)d->nx, (long long)d->ny);
-    // the Y march addresses a run of rows with 32-bit byte offsets from the run's first row
-    ARMON_REQUIRE(d->ny < (1ll << 30) && (d->nx + 2 * (int64_t)d->nghost) * (int64_t)sizeof(real) * (128 + 16) < (1ll << 32),
-                  "block too wide for 32-bit row offsets (%lld cells per row)", (long long)d->nx);
+    ARMON_REQUIRE(d->ny < (1ll << 30) && d->nx < (1ll << 30), "block too large (%lld x %lld)", (long long)d->nx, (long long)d->ny);
     const int lag = (d->scheme == ARMON_SCHEME_GAD ? 1 : 0) + (d->projection == ARMON_PROJECTION_EULER_2ND ? 1 : 0) + 2;
     ARMON_REQUIRE(d->nghost >= lag, "nghost = %d but this scheme/projection reads %d cells past the block", d->nghost, lag);
     const int64_t n_axis = d->axis == ARMON_AXIS_X ? d->nx : d->ny;
@@ -880,7 +908,10 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.c_out = d->c_out;
     const char* seg_s = getenv("ARMON_Y_SEG");                       // tuning knob, read per launch (A/B runs)
     const int seg_y_env = seg_s ? atoi(seg_s) : 0;
-    a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : y_run_length(ctx->n_cu, d->nx, n_axis));
+    a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : y_run_length(ctx->n_cu, d->nx, n_axis, lag));
+    // the Y march addresses a run of rows with 32-bit byte offsets from the run's first row
+    ARMON_REQUIRE(X || a.row_len * (int64_t)sizeof(real) * (a.seg + 2 * lag + 16) < (1ll << 32),
+                  "block too wide for 32-bit row offsets (%lld cells per row, runs of %d rows)", (long long)d->nx, a.seg);
     a.x_kernel = d->x_kernel;
     a.o_lo = 0;
     a.o_hi = n_axis;
@@ -903,6 +934,15 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
 
     int64_t n_blocks = 0;
     int rc;
+#ifdef ARMON_ONLY_HEADLINE   // variant builds for A/B timing (tools/build_variant.sh): one instantiation, seconds to compile
+    ARMON_REQUIRE(d->scheme == ARMON_SCHEME_GAD && d->limiter == ARMON_LIMITER_MINMOD && d->projection == ARMON_PROJECTION_EULER_2ND &&
+                  d->eos == ARMON_EOS_PERFECT_GAS && !exact && d->x_kernel == 0, "headline-only variant build");
+    rc = dispatch_track<fused::PipeFast<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD, ARMON_PROJECTION_EULER_2ND, ARMON_EOS_PERFECT_GAS, real>>(
+        ctx, a, d->axis, track, &n_blocks);
+    if (rc != ARMON_OK || !track) return rc;
+    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
+    return check_launch("fold_dt");
+#else
     if (d->scheme == ARMON_SCHEME_GODUNOV) {
         rc = dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact, track, &n_blocks);
     } else {
@@ -920,6 +960,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     if (rc != ARMON_OK || !track) return rc;
     hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
     return check_launch("fold_dt");
+#endif
 }
 
 // ---- placement of the 8 streamed vectors -------------------------------------------------------

@@ -22,10 +22,22 @@ class HIPDevice:
         self._L = L
         self.ctx = ctx
         self.device_id = int(device_id)
+        self.owns_ctx = True
+
+    @classmethod
+    def adopt(cls, ctx, device_id=0):
+        """Wrap an existing ``armon_ctx*`` (a tile context owned by an ``armon_mgpu`` group): never destroyed here."""
+        d = cls.__new__(cls)
+        d._L = _lib.lib()
+        d.ctx = ctx if isinstance(ctx, C.c_void_p) else C.c_void_p(ctx)
+        d.device_id = int(device_id)
+        d.owns_ctx = False
+        return d
 
     def close(self):
         if self.ctx:
-            self._L.armon_hip_destroy(self.ctx)
+            if self.owns_ctx:
+                self._L.armon_hip_destroy(self.ctx)
             self.ctx = None
 
     def __del__(self):

@@ -163,7 +163,29 @@ def _host_pack(dom, nghost, face, array, arrays, pack):
 
 
 # ---- module-level API used by solver.py ---------------------------------------------------------------------
-def setup(params, grid):
+def setup(params, grid, native=None):
+    """Create the exchanger of this rank's tile. Over RCCL (backend "nccl") the library's own multi-GPU entry points
+    are used when ``params.native_halo`` (``armon_hip_mgpu_init_rank``: RCCL send/recv on a transfer stream, ordered
+    by events only); ``native=False`` or a failed native initialisation on any rank selects the torch.distributed
+    exchanger on every rank."""
+    import torch
+    import torch.distributed as dist
+    from ._lib import SolverException
+    want = params.native_halo if native is None else native
+    if want and dist.get_backend(params.global_comm) == "nccl":
+        from .multi_tile import NativeRcclExchanger
+        comm, ok = None, 1.0
+        try:
+            comm = NativeRcclExchanger(params, grid)
+        except (SolverException, RuntimeError, AssertionError):
+            ok = 0.0
+        flag = torch.tensor([ok], device=torch.device("cuda", params.device_id))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=params.global_comm)
+        if float(flag.item()) == 1.0:
+            grid.comm = comm
+            return grid.comm
+        if comm is not None:
+            comm.close()
     grid.comm = HaloExchanger(params, grid)
     return grid.comm
 

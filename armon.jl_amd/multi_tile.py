@@ -1,0 +1,328 @@
+"""Tile-decomposed runs driven through the library's own multi-GPU entry points (include/armon_hip.h:
+``armon_hip_mgpu_init`` / ``armon_hip_halo_exchange_start|finish`` / ``armon_hip_dt_allreduce``).
+
+``TileGroup`` keeps every tile of a px × py decomposition in ONE process — the shape a Julia host without MPI, or
+a one-GPU rehearsal of the 8-GPU layout, uses: tile r on device ``device_ids[r]`` (all on device 0 by default), each
+with its own compute and transfer stream, faces moved by peer copies ordered by events only. The cycle below is the
+reference's ``solver_cycle`` (ref src/solver.jl:288-320) with ``block_ghost_exchange`` (ref src/halo_exchange.jl:
+286-368) replaced by the native exchange, the interior of each fused sweep enqueued between its start and its finish
+(the overlap the reference gets from its asynchronous block state machine, ref src/solver.jl:58-285), and the dt
+minimum reduced on the device (ref src/solver_state.jl:89-111). The host never synchronises inside a cycle.
+
+``NativeRcclExchanger`` is the one-process-per-GPU counterpart (``armon_hip_mgpu_init_rank``): the same native
+choreography over RCCL send/recv, plugged into ``solver.fused_sweep_overlapped`` in place of the torch.distributed
+``HaloExchanger``.
+"""
+import ctypes as C
+import time as _time
+
+import numpy as np
+
+from . import _lib
+from ._lib import HaloDesc, check
+from .blocking import Axis, Side, first_side, last_side, sides_along
+from .parameters import PROC_NULL, ArmonParameters
+from . import solver as S
+
+_SIDE_TAG = {Side.Left: 0, Side.Right: 1, Side.Bottom: 2, Side.Top: 3}     # ARMON_SIDE_*
+
+
+def _halo_descs(params_list, grids, names):
+    descs = (HaloDesc * len(grids))()
+    for d, p, g in zip(descs, params_list, grids):
+        d.nx, d.ny = p.N
+        d.nghost, d.nvars = p.nghost, len(names)
+        for k, f in enumerate(names):
+            d.vars[k] = g.data[f].ptr
+    return descs
+
+
+class TileGroup:
+    """All tiles of a ``P = (px, py)`` decomposition of one problem, in this process."""
+
+    def __init__(self, P, device_ids=None, **options):
+        L = _lib.lib()
+        self.P = (int(P[0]), int(P[1]))
+        nt = self.P[0] * self.P[1]
+        ids = list(device_ids) if device_ids is not None else [0] * nt
+        assert len(ids) == nt
+        self.handle = C.c_void_p()
+        check(L.armon_hip_mgpu_init(self.P[0], self.P[1], (C.c_int * nt)(*ids), C.byref(self.handle)))
+        self._L = L
+        for k in ("use_MPI", "device_id", "P"):
+            options.pop(k, None)
+        self.params, self.grids = [], []
+        for r in range(nt):
+            ctx = C.c_void_p(L.armon_hip_mgpu_ctx(self.handle, r))
+            p = ArmonParameters(**options, tile_of=(r, self.P), ctx=ctx, device_id=ids[r])
+            rank, coords, nb = C.c_int(), (C.c_int * 2)(), (C.c_int * 4)()
+            check(L.armon_hip_mgpu_tile_info(self.handle, r, C.byref(rank), C.byref(coords), C.byref(nb)))
+            # the library's topology is the reference's (and this package's) cartesian grid
+            assert rank.value == r and tuple(coords) == p.cart_coords
+            assert [p.neighbours[s] for s in (Side.Left, Side.Right, Side.Bottom, Side.Top)] == list(nb)
+            self.params.append(p)
+            self.grids.append(S.BlockGrid(p))
+        self.root = self.params[0]
+        self.global_dt = self.grids[0].global_dt
+        for g in self.grids:
+            g.global_dt = self.global_dt               # one clock for every tile (ref GlobalTimeStep is global)
+        self.dt_host = None
+        self.dt_inflight = {}
+
+    def close(self):
+        if self.handle:
+            # the tile contexts belong to the group: release everything allocated through them first
+            for g in self.grids:
+                for a in list(g.data.values()) + (list(g.alt.values()) if g.alt else []) + [g.dt_scalar]:
+                    a.free()
+            if self.dt_host is not None:
+                self.dt_host.free()
+            self._L.armon_hip_mgpu_destroy(self.handle)
+            self.handle = None
+            for p in self.params:
+                if p._device is not None:
+                    p._device.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _fn(self, name):
+        return getattr(self._L, "armon_hip_" + name + self.root.suffix)
+
+    # ---- native exchange / reduction ----------------------------------------------------------------------------
+    def exchange_start(self, axis, names):
+        check(self._fn("halo_exchange_start")(self.handle, int(axis) - 1, _halo_descs(self.params, self.grids, names)))
+
+    def exchange_finish(self, axis, names):
+        check(self._fn("halo_exchange_finish")(self.handle, int(axis) - 1, _halo_descs(self.params, self.grids, names)))
+
+    def dt_allreduce(self):
+        ptrs = (C.c_void_p * len(self.grids))(*[g.dt_scalar.ptr for g in self.grids])
+        check(self._fn("dt_allreduce")(self.handle, ptrs))
+
+    def wait(self):
+        for p in self.params:
+            p.wait()
+
+    # ---- solver ---------------------------------------------------------------------------------------------------
+    def init_test(self):
+        for p, g in zip(self.params, self.grids):
+            S.init_test(p, g)
+
+    def conservation_vars(self):
+        mass = energy = 0.
+        for p, g in zip(self.params, self.grids):
+            m, e = S.conservation_vars(p, g)
+            mass, energy = mass + m, energy + e
+        return mass, energy
+
+    def _remote(self, p, axis):
+        return (p.neighbours[first_side(axis)] != PROC_NULL, p.neighbours[last_side(axis)] != PROC_NULL)
+
+    def _fused_sweep(self, axis, dt, dx, **emit):
+        """One fused sweep of every tile: post the halos, sweep what reads no ghost cell while they travel, finish the
+        exchange, sweep the LAG-wide strips next to the remote sides."""
+        lag = S.sweep_lag(self.root)
+        i_ax = int(axis) - 1
+        any_remote = any(any(self._remote(p, axis)) for p in self.params)
+        if any_remote:
+            self.exchange_start(axis, S.STATE_VARS)
+        late = []
+        for p, g in zip(self.params, self.grids):
+            lo_r, hi_r = self._remote(p, axis)
+            n = p.N[i_ax]
+            if not (lo_r or hi_r):
+                S.fused_sweep(p, g, axis, dt, dx, swap=False, **emit)
+            elif n < 2 * lag + 1 or not p.overlap_halo:
+                late.append((p, g, None))
+            else:
+                lo, hi = (lag if lo_r else 0), (n - lag if hi_r else n)
+                S.fused_sweep(p, g, axis, dt, dx, out_range=(lo, hi), swap=False, **emit)
+                late.append((p, g, (lo, hi, n)))
+        if any_remote:
+            self.exchange_finish(axis, S.STATE_VARS)
+        for p, g, part in late:
+            if part is None:
+                S.fused_sweep(p, g, axis, dt, dx, swap=False, **emit)
+                continue
+            lo, hi, n = part
+            if lo > 0:
+                S.fused_sweep(p, g, axis, dt, dx, out_range=(0, lo), swap=False, dt_accumulate=True, **emit)
+            if hi < n:
+                S.fused_sweep(p, g, axis, dt, dx, out_range=(hi, n), swap=False, dt_accumulate=True, **emit)
+        for g in self.grids:
+            g.swap_state()
+
+    def _staged_sweep(self, axis, dt, dx):
+        for p, g in zip(self.params, self.grids):
+            S.update_EOS(p, g, axis)
+        if any(any(self._remote(p, axis)) for p in self.params):
+            self.exchange_start(axis, S.COMM_VARS)
+            self.exchange_finish(axis, S.COMM_VARS)
+        for p, g in zip(self.params, self.grids):
+            for side in sides_along(axis):
+                if p.neighbours[side] == PROC_NULL:
+                    S.boundary_conditions(p, g, axis, side)
+            S.numerical_fluxes(p, g, axis, dt, dx)
+            S.cell_update(p, g, axis, dt, dx)
+            S.projection_remap(p, g, axis, dt, dx)
+
+    def _local_dt_to_device(self):
+        """dtCFL of every tile into its device scalar (no host round trip), then the global minimum."""
+        for p, g in zip(self.params, self.grids):
+            r = p.block_size.domain_range(*p.steps_ranges[Axis.X].real_domain).to_c()
+            check(p.fn("dtCFL_async")(p.device.ctx, r, p.cell_size(0), p.cell_size(1), g.ptr("u"), g.ptr("v"),
+                                        g.ptr("c"), C.c_void_p(g.dt_scalar.ptr)))
+        self.dt_allreduce()
+
+    def _post_dt_readback(self):
+        """Tile 0's scalar (already the global minimum, ordered on its stream) into a pinned slot + event."""
+        p, g, cycle = self.root, self.grids[0], self.global_dt.cycle
+        if self.dt_host is None:
+            self.dt_host = p.device.pinned(2, p.data_type)
+        self.dt_host.copy_from_device_async(g.dt_scalar, n=1, dst_offset=cycle & 1)
+        p.device.event_record(S.DT_EVENT_SLOT + (cycle & 1))
+        self.dt_inflight[cycle] = S.DT_EVENT_SLOT + (cycle & 1)
+
+    def _take_dt_readback(self, posted_in_cycle):
+        self.root.device.event_sync(self.dt_inflight.pop(posted_in_cycle))
+        return float(self.dt_host.array[posted_in_cycle & 1])
+
+    def solver_cycle(self, last_cycle=True):
+        """ref src/solver.jl:288-320 over every tile."""
+        p0, gdt = self.root, self.global_dt
+        fused = p0.use_fused_sweep
+        deferred = (gdt.cycle - 1) in self.dt_inflight
+        if gdt.cycle == 0:
+            for p, g in zip(self.params, self.grids):
+                S.update_EOS(p, g)
+        if not deferred and not p0.cst_dt:
+            self._local_dt_to_device()
+            self._post_dt_readback()
+            gdt.update_dt(self._take_dt_readback(gdt.cycle))
+        sweeps = S.split_axes(p0.axis_splitting, gdt.cycle)
+        for k, (axis, dt_factor) in enumerate(sweeps):
+            dx = p0.cell_size(int(axis) - 1)
+            dt = gdt.current_dt * p0.T(dt_factor)
+            if not fused:
+                self._staged_sweep(axis, dt, dx)
+                continue
+            last = k == len(sweeps) - 1
+            self._fused_sweep(axis, dt, dx, emit_p=last and last_cycle, emit_dt=last and not p0.cst_dt)
+            if last and not p0.cst_dt:
+                self.dt_allreduce()
+                self._post_dt_readback()
+                if deferred:
+                    gdt.update_dt(self._take_dt_readback(gdt.cycle - 1))
+
+    def time_loop(self):
+        """ref src/solver.jl:323-403"""
+        p0, gdt = self.root, self.global_dt
+        gdt.reset()
+        self.dt_inflight.clear()
+        self.wait()
+        t1 = _time.perf_counter_ns()
+        maxtime = p0.T(p0.maxtime)
+        while gdt.time < maxtime and gdt.cycle < p0.maxcycle:
+            if p0.cst_dt:
+                ends = p0.T(gdt.time + gdt.current_dt) >= maxtime or gdt.cycle + 1 >= p0.maxcycle
+            else:
+                ends = (gdt.cycle + 1 >= p0.maxcycle or gdt.current_dt == 0
+                        or p0.T(gdt.time + gdt.current_dt) >= maxtime)
+            self.solver_cycle(last_cycle=ends)
+            gdt.next_cycle()
+        self.wait()
+        return _time.perf_counter_ns() - t1
+
+    def run(self):
+        """``armon(params)`` for the whole group → SolverStats (``data`` = this group)."""
+        self.init_test()
+        solve_ns = self.time_loop()
+        gdt, g = self.global_dt, self.root.global_grid
+        cells = g[0] * g[1]
+        return S.SolverStats(float(gdt.time), float(gdt.current_dt), gdt.cycle, solve_ns / 1e9, cells,
+                             gdt.cycle * cells / max(solve_ns, 1), data=self)
+
+    def gather(self, names=("rho", "u", "v", "E", "p")):
+        """The real cells of every tile assembled into global (NY, NX) arrays on the host."""
+        self.wait()
+        gx, gy = self.root.global_grid
+        out = {k: np.empty((gy, gx), dtype=self.root.data_type) for k in names}
+        for p, g in zip(self.params, self.grids):
+            ox, oy = p.N_origin[0] - 1, p.N_origin[1] - 1
+            nx, ny = p.N
+            for k in names:
+                out[k][oy:oy + ny, ox:ox + nx] = g.real_view(g.data[k].to_host())
+        return out
+
+
+class NativeRcclExchanger:
+    """One process per GPU: this rank's tile exchanges its halos and reduces dt through the library's RCCL group
+    (``armon_hip_mgpu_init_rank``). Same interface as ``halo_exchange.HaloExchanger`` (start / finish / exchange /
+    allreduce_min_device_async), so ``solver.fused_sweep_overlapped`` and the staged ``block_ghost_exchange`` drive
+    it unchanged. The rendezvous (128-byte RCCL ids from rank 0) travels through torch.distributed's store — the
+    launcher's job, as MPI_Bcast would be for a Julia host."""
+
+    stream_ordered = True           # everything is ordered on the device: the host never waits inside a cycle
+    native = True
+
+    def __init__(self, params, grid):
+        import torch.distributed as dist
+        L = _lib.lib()
+        self.params, self.grid, self._L = params, grid, L
+        group = params.global_comm
+        buf = C.create_string_buffer(_lib.MGPU_ID_BYTES)
+        if params.rank == 0:
+            check(L.armon_hip_mgpu_unique_id(buf))
+        obj = [bytes(buf.raw)]
+        dist.broadcast_object_list(obj, src=0, group=group)
+        ident = C.create_string_buffer(obj[0], _lib.MGPU_ID_BYTES)
+        dev = params.device                     # the tile's kernels keep running on the context the run already uses
+        self.handle = C.c_void_p()
+        check(L.armon_hip_mgpu_init_rank(params.proc_dims[0], params.proc_dims[1], params.rank, params.device_id,
+                                         C.c_void_p(dev.stream), ident, C.byref(self.handle)))
+        # the group made its own context on that same stream; sweeps stay on params.device (same stream → same order)
+        rank, coords, nb = C.c_int(), (C.c_int * 2)(), (C.c_int * 4)()
+        check(L.armon_hip_mgpu_tile_info(self.handle, 0, C.byref(rank), C.byref(coords), C.byref(nb)))
+        assert rank.value == params.rank and tuple(coords) == params.cart_coords
+        assert [params.neighbours[s] for s in (Side.Left, Side.Right, Side.Bottom, Side.Top)] == list(nb)
+
+    def _fn(self, name):
+        return getattr(self._L, "armon_hip_" + name + self.params.suffix)
+
+    def _desc(self, names):
+        return _halo_descs([self.params], [self.grid], names)
+
+    def start(self, sides, names):
+        sides = [s for s in sides if self.params.neighbours[s] != PROC_NULL]
+        if not sides:
+            return None
+        axis = Axis.X if sides[0] in (Side.Left, Side.Right) else Axis.Y
+        check(self._fn("halo_exchange_start")(self.handle, int(axis) - 1, self._desc(names)))
+        return axis, tuple(names)
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        axis, names = handle
+        check(self._fn("halo_exchange_finish")(self.handle, int(axis) - 1, self._desc(names)))
+
+    def exchange(self, sides, names):
+        self.finish(self.start(sides, names))
+
+    def allreduce_min_device_async(self, scalar):
+        ptrs = (C.c_void_p * 1)(scalar.ptr)
+        check(self._fn("dt_allreduce")(self.handle, ptrs))
+
+    def allreduce_host(self, values, op):
+        v = (C.c_double * len(values))(*values)
+        check(self._L.armon_hip_mgpu_allreduce_host(self.handle, 0 if op == "sum" else 1, len(values), v))
+        return list(v)
+
+    def close(self):
+        if self.handle:
+            self._L.armon_hip_mgpu_destroy(self.handle)
+            self.handle = None

@@ -119,7 +119,12 @@ class ArmonParameters:
     # gloo in CPU tests): `use_MPI=True` needs an initialised process group, `global_comm` may carry a
     # torch ProcessGroup. Default is False here because a single process owns a single GPU.
     def _init_MPI(self, use_MPI=False, P=(1, 1), reorder_grid=True, global_comm=None, gpu_aware=True,
-                  **options):
+                  tile_of=None, **options):
+        """``tile_of=(rank, (px, py))``: this parameter set describes ONE tile of a px×py grid whose tiles all live in
+        this process (``multi_tile.TileGroup`` over ``armon_hip_mgpu_init``): same partition and neighbours as an MPI
+        rank of the reference, no process group involved."""
+        if tile_of is not None:
+            P = tile_of[1]
         if len(P) != len(self.N):
             solver_error("config", f"Mismatched dimensions: expected a grid of {len(self.N)} processes, got: {len(P)}")
         self.use_MPI = bool(use_MPI)
@@ -136,6 +141,14 @@ class ArmonParameters:
             if self.proc_dims[0] * self.proc_dims[1] != self.proc_size:
                 solver_error("config", f"could not create a {P[0]}×{P[1]} cartesian topology "
                                        f"using {self.proc_size} processes")
+            self.cart_coords = cart_coords(self.rank, self.proc_dims)
+            self.neighbours = cart_neighbours(self.cart_coords, self.proc_dims)
+        elif tile_of is not None:
+            self.proc_dims = tuple(int(p) for p in P)
+            self.rank = int(tile_of[0])
+            self.proc_size = self.proc_dims[0] * self.proc_dims[1]
+            if not 0 <= self.rank < self.proc_size:
+                solver_error("config", f"tile {self.rank} is not part of a {P[0]}×{P[1]} grid")
             self.cart_coords = cart_coords(self.rank, self.proc_dims)
             self.neighbours = cart_neighbours(self.cart_coords, self.proc_dims)
         else:
@@ -206,7 +219,8 @@ class ArmonParameters:
 
     # ref src/parameters.jl:766-778 — backend specific options (like ext/ArmonKokkos.jl:83-87)
     def _init_backend(self, device_id=None, use_fused_sweep=True, exact_arithmetic=False, stream=None,
-                      placement_tries=12, stream_ordered_halo=True, **options):
+                      placement_tries=12, stream_ordered_halo=True, ctx=None, native_halo=True, overlap_halo=True,
+                      **options):
         """``device_id``: GPU ordinal (default LOCAL_RANK or 0). ``use_fused_sweep``: run each sweep as
         the fused HIP kernel instead of the 5 staged kernels. ``exact_arithmetic=True``: IEEE division/sqrt
         and no FMA contraction in the fused sweep (bit-identical to the staged path and to the CPU oracle);
@@ -219,6 +233,9 @@ class ArmonParameters:
             device_id = int(os.environ.get("LOCAL_RANK", "0")) if self.use_MPI else 0
         self.device_id = int(device_id)
         self._stream = stream
+        self._ctx = ctx         # an existing armon_ctx to adopt (a tile context owned by an armon_mgpu group)
+        self.native_halo = bool(native_halo)    # N>1 over RCCL: halo exchange / dt all-reduce by the library itself
+        self.overlap_halo = bool(overlap_halo)  # sweep the interior while the halos travel
         self._device = None     # created on first use, so that configuration errors need no GPU
         # per-step dumps / comparisons need the intermediate states: only the staged path has them
         self.use_fused_sweep = bool(use_fused_sweep) and not self.compare
@@ -236,6 +253,9 @@ class ArmonParameters:
         """``create_device(Val(:HIP_native))`` (ref src/parameters.jl:751-755): context on first use."""
         if self._device is None:
             from .device import HIPDevice
+            if self._ctx is not None:
+                self._device = HIPDevice.adopt(self._ctx, self.device_id)
+                return self._device
             stream = self._stream
             if stream is None and self.use_MPI and self.stream_ordered_halo:
                 stream = self._torch_stream_for_rccl()

@@ -2,6 +2,11 @@
 """Benchmark of the direction-split sweep hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus 4 --global 32768x16384 --grid 2x2            BASELINE config 4 (= --config 4)
+    python bench.py --gpus 8 --test Bizarrium --global 32768x32768 --grid 4x2      config 5 (= --config 5)
+    python bench.py --gpus N --strong                      fixed 16384² global grid split over N GPUs
+
+Default (no --global): WEAK scaling, --cells² cells per GPU on the process grid 1→1x1, 2→2x1, 4→2x2, 8→4x2.
 
 A "step" is one solver cycle of the reference's time loop (ref src/solver.jl:288-320): the dt/CFL
 reduction + one X sweep + one Y sweep over the whole grid. Inputs are the reference's own deterministic
@@ -58,18 +63,24 @@ class EventTimer:
         return out
 
 
-def pmc_traffic(args, world):
-    """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_traffic_*.json, made by tools/pmc_to_traffic.py) — only for the exact workload
-    they were collected on; otherwise null."""
-    if world != 1 or args.staged or args.exact or args.f32 or args.n != 16384 or args.test != "Sod" or args.scheme != "GAD":
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fused_fast_sod16384.json")
-    try:
-        ks = json.load(open(path))["kernels"]
-        return round(sum(k["traffic_bytes_per_launch"] for k in ks.values()) / len(ks))
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
-        return None
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic_fused_fast_sod16384.json"
+
+
+def pmc_traffic(args, world, N_global):
+    """HBM bytes per launch of the dominant kernels. Hardware counters cannot be read from inside this process:
+    the figure is REPLAYED from the committed rocprofv3 --pmc passes of this same command (PMC_TRAFFIC_FILE, made by
+    tools/pmc.sh + tools/pmc_to_traffic.py) — only for the exact workload they were collected on, otherwise null.
+    Returns (bytes, source)."""
+    if (world != 1 or args.staged or args.exact or args.f32 or tuple(N_global) != (16384, 16384) or args.test != "Sod"
+            or args.scheme != "GAD"):
+        return None, None
+    for rel in (PMC_TRAFFIC_FILE, "profiles/r01_pmc_traffic_fused_fast_sod16384.json"):
+        try:
+            ks = json.load(open(os.path.join(ROOT, rel)))["kernels"]
+            return round(sum(k["traffic_bytes_per_launch"] for k in ks.values()) / len(ks)), rel + " (replayed, not measured in this run)"
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            continue
+    return None, None
 
 
 def usable_cores():
@@ -117,7 +128,24 @@ def main():
     ap.add_argument("--fast", action="store_true", help="(default) tuned arithmetic; kept for compatibility")
     ap.add_argument("--f32", action="store_true", help="Float32 data_type (the _f32 entry points) instead of the fp64 headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global", dest="global_grid", default=None, metavar="NXxNY",
+                    help="GLOBAL grid, split over the process grid (tiles = N÷P, remainder on the last tile, ref "
+                         "src/parameters.jl:673-697); default: --cells² per GPU (weak scaling)")
+    ap.add_argument("--grid", default=None, metavar="PXxPY", help="process grid (default: 1x1, 2x1, 2x2, 4x2 for 1, 2, 4, 8 ranks)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the global grid stays --cells² (or --global) whatever the number of GPUs")
+    ap.add_argument("--config", type=int, choices=(2, 3, 4, 5), default=None,
+                    help="BASELINE.json configs[N-1]: 2 = Sod 8192² Godunov, 3 = Sedov 16384², "
+                         "4 = Sod 32768x16384 on 2x2, 5 = Bizarrium 32768² on 4x2")
     args = ap.parse_args()
+    if args.config == 2:
+        args.test, args.scheme, args.n = "Sod", "Godunov", 8192
+    elif args.config == 3:
+        args.test, args.n = "Sedov", 16384
+    elif args.config == 4:
+        args.test, args.global_grid, args.grid = "Sod", "32768x16384", "2x2"
+    elif args.config == 5:
+        args.test, args.global_grid, args.grid = "Bizarrium", "32768x32768", "4x2"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -145,8 +173,18 @@ def main():
     from armon_amd.parameters import proc_grid_for
     from armon_amd.solver import BlockGrid, init_test, solver_cycle
 
-    P = proc_grid_for(world)                                  # (px, py), e.g. 8 → (4, 2)
-    N_global = (args.n * P[0], args.n * P[1])                 # weak scaling: n×n cells per GPU
+    P = tuple(int(v) for v in args.grid.lower().split("x")) if args.grid else proc_grid_for(world)   # (px, py), e.g. 8 → (4, 2)
+    if len(P) != 2 or P[0] * P[1] != world:
+        sys.exit(f"--grid {args.grid}: {world} rank(s) cannot form that process grid")
+    if args.global_grid:
+        N_global = tuple(int(v) for v in args.global_grid.lower().split("x"))
+        scaling = "strong"                                    # a named global grid: total work is fixed
+    elif args.strong:
+        N_global = (args.n, args.n)                           # strong scaling: the same n×n grid whatever the GPU count
+        scaling = "strong"
+    else:
+        N_global = (args.n * P[0], args.n * P[1])             # weak scaling: n×n cells per GPU
+        scaling = "weak"
     params = armon_amd.ArmonParameters(
         test=args.test, N=N_global, scheme=args.scheme, riemann_limiter="minmod", projection="euler_2nd",
         axis_splitting="Sequential", nghost=4, maxtime=1e9, maxcycle=10 ** 9, silent=5,
@@ -160,18 +198,25 @@ def main():
     gdt = grid.global_dt
     gdt.reset()
 
-    # N > 1 over RCCL: the stream-ordered halo exchange (no host synchronisation) is checked on THIS machine against
-    # the host-synchronised protocol before anything is timed: a few cycles in each mode from the same initial state
-    # must give the same dt sequence and the same global mass / energy, bit for bit; if not, the timed run uses
-    # the host-synchronised protocol and says so.
+    # N > 1 over RCCL: three ways to move the halos, fastest first — (1) the library's own multi-GPU entry points
+    # (armon_hip_halo_exchange_start/finish + armon_hip_dt_allreduce: RCCL send/recv on a transfer stream, events
+    # only), (2) torch.distributed's RCCL ordered on the kernels' stream, (3) torch.distributed with host
+    # synchronisation (the reference's MPI protocol). (1) and (2) never wait on the host, so they are checked on THIS
+    # machine against (3) before anything is timed: five cycles from the same initial state must give the same dt
+    # sequence and the same global mass / energy bit for bit on every rank; the first that does is used and named.
     halo_mode = None
     if dist is not None and grid.comm is not None:
-        halo_mode = "stream-ordered" if grid.comm.stream_ordered else "host-synchronised"
-        if grid.comm.stream_ordered:
-            from armon_amd.solver import conservation_vars, drain_halo
+        from armon_amd.halo_exchange import HaloExchanger, allreduce_min
+        from armon_amd.solver import conservation_vars, drain_halo
+        native_comm = grid.comm if getattr(grid.comm, "native", False) else None
+        torch_comm = grid.comm if native_comm is None else HaloExchanger(params, grid)
+        halo_mode = "host-synchronised (gloo rehearsal: every rank on one GPU, host staging)"
+        if torch_comm.stream_ordered or native_comm is not None:
 
-            def probe(stream_ordered, cycles=5):
-                grid.comm.stream_ordered = stream_ordered
+            def probe(comm, stream_ordered, cycles=5):
+                grid.comm = comm
+                if comm is torch_comm:
+                    comm.stream_ordered = stream_ordered
                 init_test(params, grid, tune=False)
                 gdt.reset()
                 grid.dt_inflight.clear()
@@ -184,14 +229,32 @@ def main():
                 params.wait()
                 return dts, conservation_vars(params, grid)
 
-            ref = probe(False)
-            got = probe(True)
-            same = 1.0 if ref == got else 0.0
-            from armon_amd.halo_exchange import allreduce_min
-            same = allreduce_min(params, same)
-            grid.comm.stream_ordered = same == 1.0
-            halo_mode = ("stream-ordered (self-check against the host-synchronised protocol passed)" if same == 1.0
-                         else "host-synchronised (the stream-ordered self-check FAILED on this machine)")
+            could_order = torch_comm.stream_ordered
+            ref = probe(torch_comm, False)
+            halo_mode, chosen = None, None
+            candidates = ([("native (armon_hip_halo_exchange over RCCL send/recv on a transfer stream, "
+                            "armon_hip_dt_allreduce; device-ordered)", native_comm, True)] if native_comm else [])
+            if could_order:
+                candidates.append(("torch.distributed RCCL, stream-ordered", torch_comm, True))
+            failed = []
+            for name, comm, so in candidates:
+                try:
+                    same = 1.0 if probe(comm, so) == ref else 0.0
+                except Exception as e:          # a transport that cannot run here must not cost the bench line
+                    same = 0.0
+                    failed.append(f"{name.split(' ')[0]}: {type(e).__name__}")
+                if allreduce_min(params, same) == 1.0:
+                    halo_mode, chosen = name + " — self-check against the host-synchronised protocol passed", (comm, so)
+                    break
+                failed.append(name.split(" ")[0] + " self-check FAILED")
+            if chosen is None:
+                chosen = (torch_comm, False)
+                halo_mode = "torch.distributed RCCL, host-synchronised (" + "; ".join(failed) + ")"
+            elif failed:
+                halo_mode += " (" + "; ".join(failed) + ")"
+            grid.comm = chosen[0]
+            if chosen[0] is torch_comm:
+                torch_comm.stream_ordered = chosen[1]
             init_test(params, grid, tune=False)
             gdt.reset()
             grid.dt_inflight.clear()
@@ -273,8 +336,9 @@ def main():
     mean_ms = sum(all_ms) / max(sweeps_timed, 1)
     bpc = B_PER_CELL[dominant[0]] // (2 if args.f32 else 1)
     achieved = bpc * cells_local / (mean_ms * 1e-3) / 1e9 if all_ms else 0.0
+    traffic, traffic_source = pmc_traffic(args, world, N_global)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args, world),
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "+".join(dominant), "bytes_per_cell": bpc, "launches_timed": len(all_ms),
                 "sweeps_timed": sweeps_timed, "mean_launch_ms": round(mean_ms, 4),
                 "per_kernel_ms": {k: round(sum(v) / max(cycles_timed * (2 if args.staged else 1), 1), 4)
@@ -287,10 +351,13 @@ def main():
     out = {
         "metric": f"Mcells/sec per sweep ({prec})", "value": round(value, 1), "unit": "Mcells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if scaling == "strong" else "weak",
         "vs_baseline": None, "dtype": "f32" if args.f32 else "f64", "data": "synthetic",
         "config": {"workload": f"{args.test} {N_global[0]}x{N_global[1]} {prec}, {args.scheme}+minmod+euler_2nd, "
-                               f"Sequential X,Y splitting, nghost 4, {args.n}x{args.n} cells per GPU",
+                               f"Sequential X,Y splitting, nghost 4, {P[0]}x{P[1]} tiles of {params.N[0]}x{params.N[1]} cells "
+                               f"({scaling} scaling)",
+                   "baseline_config": args.config,
                    "path": "staged (5 kernels/sweep)" if args.staged else "fused sweep",
                    "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",

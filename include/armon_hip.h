@@ -347,6 +347,71 @@ ARMON_API int armon_hip_sweep_f32(armon_ctx*, const armon_sweep_desc_f32*);
 ARMON_API int armon_hip_tune_placement_f32(armon_ctx*, const armon_sweep_desc_f32* x_desc, const armon_sweep_desc_f32* y_desc,
         void* const* pool, int n_pool, size_t bytes, int tries, int picks[8], double* times_ms);
 
+
+/* ---- multi-GPU: tile-decomposed grid, halo exchange and dt reduction on the device ------------------------------ */
+/* Replaces the reference's MPI path: start_exchange / finish_exchange (ref src/halo_exchange.jl:229-283), the side
+ * selection of block_ghost_exchange (ref :323-354: the two sides ALONG the sweep axis, all ghost layers, no corners),
+ * the MPI_Iallreduce(MIN) of the time step (ref src/solver_state.jl:89-111, src/utils.jl:126-143) and the cartesian
+ * topology of init_MPI (ref src/parameters.jl:441-447: rank r at coords (r / py, r % py), non-periodic).
+ *
+ * A group is a px x py grid of tiles. Each local tile owns an armon_ctx (its compute stream: enqueue that tile's
+ * kernels there) and a transfer stream. An exchange is pack -> (event) -> transfer -> (event) -> unpack, ordered on
+ * the device only: NO host synchronisation between pack and unpack, so whatever the caller enqueues on a tile's
+ * compute stream between _start and _finish (the interior of a fused sweep) overlaps with the transfers.
+ *  - armon_hip_mgpu_init      : every tile lives in this process, tile r on device device_ids[r] (devices may repeat;
+ *                               NULL = all on device 0). Faces travel as peer-to-peer copies (xGMI between GPUs).
+ *  - armon_hip_mgpu_init_rank : one process per GPU; this process owns tile `rank` only. Faces travel as RCCL
+ *                               send/recv pairs, the dt minimum as an RCCL all-reduce. `id` = ARMON_MGPU_ID_BYTES bytes
+ *                               from armon_hip_mgpu_unique_id on rank 0, broadcast by the host's own launcher
+ *                               (MPI_Bcast in Armon.jl, the torch.distributed store in bench.py). Collective.
+ *                               `stream`: compute stream to adopt, or NULL. */
+typedef struct armon_mgpu armon_mgpu;
+#define ARMON_MGPU_ID_BYTES 256
+
+ARMON_API int armon_hip_mgpu_init(int px, int py, const int* device_ids, armon_mgpu** group);
+ARMON_API int armon_hip_mgpu_unique_id(void* id);
+ARMON_API int armon_hip_mgpu_init_rank(int px, int py, int rank, int device_id, void* stream, const void* id,
+                                       armon_mgpu** group);
+ARMON_API int armon_hip_mgpu_destroy(armon_mgpu* group);
+ARMON_API int armon_hip_mgpu_n_local(armon_mgpu* group);                       /* tiles owned by this process */
+ARMON_API armon_ctx* armon_hip_mgpu_ctx(armon_mgpu* group, int local_tile);    /* that tile's context (owned by the group) */
+/* rank, cartesian coords and the neighbour rank per ARMON_SIDE_* (-1 = physical boundary, MPI.PROC_NULL) */
+ARMON_API int armon_hip_mgpu_tile_info(armon_mgpu* group, int local_tile, int* rank, int coords[2], int neighbours[4]);
+
+/* What one local tile exchanges: fused path (rho,u,v,E); staged path comm_vars (rho,u,v,E,p,c,g), ref
+ * src/blocking/blocks.jl:50. The wire format is pack_to_array!'s (ref src/halo_exchange.jl:187-216). */
+typedef struct {
+    int64_t nx, ny;          /* real cells of the tile                              */
+    int32_t nghost, nvars;   /* ghost layers; number of vectors (1..8)              */
+    void*   vars[8];         /* device vectors of (nx+2g)*(ny+2g) elements          */
+} armon_halo_desc;
+
+/* `tiles` = one descriptor per LOCAL tile, in local tile order. _start packs and posts the transfers of the two
+ * sides along `axis` of every local tile that has a neighbour there; _finish makes each compute stream wait for its
+ * receives and unpacks them into the ghost cells; armon_hip_halo_exchange = _start + _finish. Physical sides are
+ * left alone (mirror boundary condition: armon_hip_boundary_conditions, or bc_low/bc_high of the fused sweep). */
+ARMON_API int armon_hip_halo_exchange_start(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+ARMON_API int armon_hip_halo_exchange_finish(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+ARMON_API int armon_hip_halo_exchange(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+ARMON_API int armon_hip_halo_exchange_start_f32(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+ARMON_API int armon_hip_halo_exchange_finish_f32(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+ARMON_API int armon_hip_halo_exchange_f32(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+
+/* Global minimum of one device scalar per local tile (dt_cfl_out of the fused sweep / armon_hip_dtCFL_async), in
+ * place, ordered on the compute streams: afterwards every dt_dev[k] holds the minimum over ALL tiles of the group.
+ * The reference consumes it one cycle later (ref src/solver_state.jl:145-166): nothing is waited for on the host. */
+ARMON_API int armon_hip_dt_allreduce(armon_mgpu*, double* const* dt_dev);
+ARMON_API int armon_hip_dt_allreduce_f32(armon_mgpu*, float* const* dt_dev);
+
+/* Host-value all-reduce over the PROCESSES of the group (the conservation sums, ref src/reductions.jl:317-320);
+ * op 0 = sum, 1 = min; count <= 16; synchronous; the caller folds its own local tiles first. */
+ARMON_API int armon_hip_mgpu_allreduce_host(armon_mgpu*, int op, int count, double* values);
+
+/* border_domain(bsize, side) / ghost_domain(bsize, side) with all ghost layers (ref src/blocking/blocking.jl:141-187,
+ * single_strip=false) and real_face_size (ref :210) of a tile of nx x ny real cells, 0-based; outputs nullable. */
+ARMON_API int armon_hip_halo_ranges(int64_t nx, int64_t ny, int nghost, int side, armon_range* border,
+                                    armon_range* ghost, int64_t* face);
+
 #ifdef __cplusplus
 }
 #endif

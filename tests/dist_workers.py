@@ -93,6 +93,7 @@ def gpu_solver_worker(rank, world, port, P, N_global, test, opts, out_dir, backe
         assert params.shared_stream and stats.data.comm.stream_ordered
     host = stats.data.device_to_host(("rho", "u", "v", "E", "p"))
     np.savez(os.path.join(out_dir, f"tile{rank}.npz"), cycles=stats.cycles, dt=stats.last_dt, time=stats.final_time,
+             native=bool(getattr(stats.data.comm, "native", False)),
              origin=np.array(params.N_origin), n=np.array(params.N),
              **{k: stats.data.real_view(v) for k, v in host.items()})
     dist.destroy_process_group()

@@ -119,3 +119,90 @@ def test_sod_16384_f32(oracle, exact):
         else:
             assert np.abs(a[0].astype(np.float64) - o).max() <= 2e-5 * np.abs(o).max(), k
         del a
+
+
+# ---- BASELINE.json configs 2, 3 and 5's test case at their full single-GPU sizes -----------------------------------
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+def test_config2_sod_8192_godunov_fused(oracle, exact):
+    """BASELINE configs[1]: Sod 8192² with the first-order acoustic solver (scheme=Godunov, projection euler_2nd),
+    fused sweep: rows identical, equal to the oracle's 8192×8 strip (bit for bit / tuned tolerance), conservation."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, conservation_vars, init_test, time_loop
+    n = 8192
+    orun, f = oracle.solve(test="Sod", N=(n, 8), domain_size=(1., 8. / n), maxcycle=CYCLES, threads=8, scheme="Godunov")
+    params = armon_amd.ArmonParameters(test="Sod", N=(n, n), maxcycle=CYCLES, silent=5, scheme="Godunov",
+                                       exact_arithmetic=exact)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    m0, e0 = conservation_vars(params, grid)
+    time_, dt, cycles, _, _ = time_loop(params, grid)
+    m1, e1 = conservation_vars(params, grid)
+    assert abs(m1 - m0) <= 1e-11 * abs(m0) and abs(e1 - e0) <= 1e-11 * abs(e0)
+    assert cycles == orun.cycles == CYCLES
+    if exact:
+        assert dt == orun.last_dt and time_ == orun.final_time
+    else:
+        assert abs(dt - orun.last_dt) <= 1e-12 * orun.last_dt
+    for k in NAMES:
+        a = grid.real_view(grid.data[k].to_host())
+        o = oracle.real_view(f[k], n, 8, G)[0]
+        assert np.array_equal(a, np.broadcast_to(a[0:1], a.shape)), f"{k}: rows differ"
+        if exact:
+            assert np.array_equal(a[0], o), k
+        else:
+            assert np.abs(a[0] - o).max() <= 1e-11 * np.abs(o).max(), k
+        del a
+
+
+def test_config3_sedov_16384_tuned_symmetry_and_conservation():
+    """BASELINE configs[2]: Sedov 16384² GAD+minmod+euler_2nd, tuned arithmetic (no strip reduction exists: the blast
+    radius scales with the cell size). Checked at full size:
+    * against the EXACT arithmetic of the same kernels at the same size (itself bit-identical to the oracle wherever
+      the oracle can follow): same cycle count, dt within 1e-12, fields within 1e-11 of the field maximum;
+    * mirror symmetry x→−x and y→−y — ρ, E, p even; u odd in x, v odd in y. The reference's own formula breaks exact
+      symmetry in the GAD velocity ratios (the +1e-6 in their denominators, ref src/riemann_schemes.jl:84-87, does not
+      change sign with the velocities), so the bound is SYM_TOL of the field maximum, not zero;
+    * mass and energy conserved to 1e-11 (ref test/conservation.jl); the blast has formed and has not reached far cells."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, conservation_vars, init_test, time_loop
+    SYM_TOL, cyc = 1e-6, 12
+    fields = {}
+    for exact in (True, False):
+        params = armon_amd.ArmonParameters(test="Sedov", N=(N, N), maxcycle=cyc, silent=5, exact_arithmetic=exact)
+        grid = BlockGrid(params)
+        init_test(params, grid)
+        m0, e0 = conservation_vars(params, grid)
+        time_, dt, cycles, _, _ = time_loop(params, grid)
+        m1, e1 = conservation_vars(params, grid)
+        assert cycles == cyc and dt > 0 and time_ > 0
+        assert abs(m1 - m0) <= 1e-11 * abs(m0) and abs(e1 - e0) <= 1e-11 * abs(e0)
+        fields[exact] = (dt, {k: grid.real_view(grid.data[k].to_host()).copy() for k in NAMES})
+        del grid, params
+    (dt_e, fe), (dt_t, ft) = fields[True], fields[False]
+    assert abs(dt_t - dt_e) <= 1e-12 * dt_e
+    for k, sx, sy in (("rho", 1, 1), ("E", 1, 1), ("p", 1, 1), ("u", -1, 1), ("v", 1, -1)):
+        a, scale = ft[k], np.abs(fe[k]).max()
+        assert np.isfinite(a).all(), k
+        assert np.abs(a - fe[k]).max() <= 1e-11 * scale, f"{k}: tuned vs exact arithmetic"
+        assert np.abs(a - sx * a[:, ::-1]).max() <= SYM_TOL * scale, f"{k}: x -> -x symmetry"
+        assert np.abs(a - sy * a[::-1, :]).max() <= SYM_TOL * scale, f"{k}: y -> -y symmetry"
+    rho, c = ft["rho"], N // 2
+    assert (rho > 0).all() and (ft["E"] > 0).all()
+    assert np.unique(rho[c - 40:c + 40, c - 40:c + 40]).size > 50                  # the blast wave has formed
+    assert (rho[:c - 200] == 1.0).all() and (rho[:, :c - 200] == 1.0).all()        # and has not reached far cells
+
+
+def test_config5_bizarrium_16384_tuned(oracle):
+    """BASELINE configs[4]'s test case on one GPU, tuned arithmetic: rows identical, within the tuned tolerance of
+    the oracle's 16384×8 strip, same cycle count."""
+    import armon_amd
+    orun, f = oracle.solve(test="Bizarrium", N=(N, 8), domain_size=(1., 8. / N), maxcycle=CYCLES, threads=8)
+    params = armon_amd.ArmonParameters(test="Bizarrium", N=(N, N), maxcycle=CYCLES, silent=5, return_data=True)
+    stats = armon_amd.armon(params)
+    assert stats.cycles == orun.cycles and abs(stats.last_dt - orun.last_dt) <= 1e-12 * orun.last_dt
+    for k in NAMES:
+        a = stats.data.real_view(stats.data.data[k].to_host())
+        o = oracle.real_view(f[k], N, 8, G)[0]
+        assert np.array_equal(a, np.broadcast_to(a[0:1], a.shape)), f"{k}: rows differ"
+        assert np.abs(a[0] - o).max() <= 1e-11 * np.abs(o).max(), k
+        del a
