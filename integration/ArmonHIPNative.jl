@@ -1,177 +1,363 @@
 # ArmonHIPNative.jl — package extension binding libarmon_hip.so into Armon.jl (Keluaa/Armon.jl @ 2024_08_07).
 #
-# NOT EXECUTED in the build image (no `julia` there): written against the reference's sources, following its own
-# Kokkos extension (ext/ArmonKokkos.jl). The ABI it binds is exercised end to end by the Python host
-# (armon.jl_amd/_lib.py, tests/) and by examples/native_cycle.c. See INTEGRATION.md for the walk-through.
+# NOT EXECUTED in the build image (no `julia` there). Written against the reference's sources, following its own
+# Kokkos extension (ext/ArmonKokkos.jl). What CAN be checked without Julia is checked by tests/test_julia_binding.py:
+# every `ccall(fn(:armon_hip_…), ret, (argtypes…), …)` below is parsed and compared — symbol, arity, C type of every
+# argument and of the return value — with include/armon_hip.h as bound by armon.jl_amd/_lib.py (SIGNATURES), and the
+# struct mirrors (CRange, CBlockData, SweepDesc, HaloDesc) with the ctypes structures field by field.
+# The ABI itself is exercised end to end by the Python host (tests/) and by examples/native_cycle.c.
 #
-# Install: copy to Armon.jl/ext/, declare it in Project.toml ([extensions] ArmonHIPNative = ...), then
-#   ArmonParameters(; use_gpu=true, device=:HIP_native, use_cache_blocking=false, armon_hip_lib="/path/libarmon_hip.so", ...)
+# Install: copy to Armon.jl/ext/, declare it in Project.toml ([weakdeps]/[extensions] ArmonHIPNative = "Libdl"), then
+#   ArmonParameters(; use_gpu=true, device=:HIP_native, use_cache_blocking=false, async_cycle=false,
+#                     armon_hip_lib="/path/libarmon_hip.so", ...)
 module ArmonHIPNative
 
 using Armon
-import Armon: ArmonParameters, BlockData, DomainRange, SolverState, LocalTaskBlock, Side, Axis
+using Libdl
+import Armon: ArmonParameters, BlockGrid, BlockData, DomainRange, SolverState, LocalTaskBlock, Side, Axis
 import Armon: create_device, init_backend, device_array_type, host_array_type, device_memory_info,
               print_device_info, solver_error, block_device_data, block_domain_range, stride_along,
-              ghosts, real_face_size, limiter_from_name
+              ghosts, real_face_size, real_block_size, block_size, first_sides, first_side, last_side, has_neighbour,
+              boundary_condition, specific_heat_ratio, all_blocks, first_state, split_axes, update_solver_state!,
+              update_EOS!, next_time_step, contribute_to_dt!, solver_cycle
 import Armon: perfect_gas_EOS!, bizarrium_EOS!, acoustic!, acoustic_GAD!, cell_update!,
               advection_first_order!, advection_second_order!, euler_projection!, boundary_conditions!,
               pack_to_array!, unpack_from_array!, dtCFL_kernel, conservation_vars, init_test
 
-const lib = Ref{String}("libarmon_hip.so")          # path set by init_backend(armon_hip_lib=...)
-
-# ---- device object + device array type -------------------------------------------------------------------
-mutable struct HIPNative                             # becomes the `Device` parameter of ArmonParameters
-    ctx::Ptr{Cvoid}
+# ---- library handle and symbol lookup -------------------------------------------------------------------------
+const LIB = Ref{Ptr{Cvoid}}(C_NULL)                 # dlopen handle, set by init_backend(armon_hip_lib=...)
+const SYMS = Dict{Symbol, Ptr{Cvoid}}()
+function fn(name::Symbol)                           # fp64 entry point
+    get!(SYMS, name) do
+        LIB[] == C_NULL && (LIB[] = Libdl.dlopen("libarmon_hip.so"))
+        Libdl.dlsym(LIB[], name)
+    end
 end
-
-"Flat device vector: what `device_array_type(dev){T,1}(undef, n)` must return (src/blocking/blocks.jl:36-44)."
-mutable struct HIPVector{T} <: AbstractVector{T}
-    ptr::Ptr{T}; n::Int; dev::HIPNative
-end
-function HIPVector{T,1}(::UndefInitializer, n::Integer) where T     # ref src/blocking/block_grid.jl:52-57
-    dev = CURRENT_DEVICE[]; p = Ref{Ptr{Cvoid}}()
-    check(ccall((:armon_hip_malloc, lib[]), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Ptr{Cvoid}}), dev.ctx, n*sizeof(T), p))
-    v = HIPVector{T}(Ptr{T}(p[]), n, dev)
-    finalizer(x -> ccall((:armon_hip_free, lib[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.dev.ctx, x.ptr), v)
-end
-Base.size(v::HIPVector) = (v.n,)
-Base.unsafe_convert(::Type{Ptr{T}}, v::HIPVector{T}) where T = v.ptr
-# copyto! both ways (ref device_to_host!/host_to_device!, src/blocking/blocks.jl:121-143)
-Base.copyto!(dst::Vector{T}, src::HIPVector{T}) where T = (check(ccall((:armon_hip_memcpy, lib[]), Cint,
-    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), src.dev.ctx, dst, src.ptr, sizeof(dst), 2)); dst)
-Base.copyto!(dst::HIPVector{T}, src::Vector{T}) where T = (check(ccall((:armon_hip_memcpy, lib[]), Cint,
-    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), dst.dev.ctx, dst.ptr, src, sizeof(src), 1)); dst)
+fn(name::Symbol, ::Type{Float64}) = fn(name)
+fn(name::Symbol, ::Type{Float32}) = fn(Symbol(name, :_f32))     # data_type=Float32: same symbols, `_f32` suffix
 
 check(rc) = rc == 0 ? nothing :                      # ref ext/ArmonKokkos.jl:72-76, src/utils.jl:108
-    solver_error(:cpp, unsafe_string(ccall((:armon_hip_last_error, lib[]), Cstring, ())))
+    solver_error(rc == 4 ? :time : :cpp, unsafe_string(ccall(fn(:armon_hip_last_error), Cstring, ())))
 
-# ---- backend hooks (ref src/parameters.jl:751-802,921-951,1031-1038) ---------------------------------------
-const CURRENT_DEVICE = Ref{HIPNative}()
-function create_device(::Val{:HIP_native})
-    ctx = Ref{Ptr{Cvoid}}()
-    check(ccall((:armon_hip_init, lib[]), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), 0, C_NULL, ctx))
-    @assert ccall((:armon_hip_flt_size, lib[]), Cint, ()) == 8      # ref ext/ArmonKokkos.jl:122-139
-    @assert ccall((:armon_hip_idx_size, lib[]), Cint, ()) == 8
-    CURRENT_DEVICE[] = HIPNative(ctx[])
+# ---- device object + device array type -------------------------------------------------------------------------
+mutable struct HIPNative                             # becomes the `Device` parameter of ArmonParameters
+    ctx::Ptr{Cvoid}
+    device_id::Int
 end
-init_backend(params::ArmonParameters, ::HIPNative; armon_hip_lib = nothing, options...) =
-    (isnothing(armon_hip_lib) || (lib[] = armon_hip_lib); params.backend_options = nothing; options)
-device_array_type(::HIPNative) = HIPVector
-host_array_type(::HIPNative) = Vector
+const CURRENT_DEVICE = Ref{HIPNative}()
+
+"""
+Flat device array: `device_array_type(dev){T, 1}(undef, n)` of ref src/blocking/block_grid.jl:52-57 — the reference
+applies `{T, 1}` to the type this returns, so it takes the element type AND the rank as parameters.
+"""
+mutable struct HIPVector{T, N} <: AbstractArray{T, N}
+    ptr::Ptr{T}
+    dims::NTuple{N, Int}
+    dev::HIPNative
+    function HIPVector{T, N}(::UndefInitializer, dims::NTuple{N, Integer}; kwargs...) where {T, N}   # kwargs: alloc_array_kwargs
+        dev = CURRENT_DEVICE[]
+        p = Ref{Ptr{Cvoid}}()
+        check(ccall(fn(:armon_hip_malloc), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Ptr{Cvoid}}), dev.ctx, prod(dims) * sizeof(T), p))
+        v = new{T, N}(Ptr{T}(p[]), Int.(dims), dev)
+        finalizer(x -> ccall(fn(:armon_hip_free), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.dev.ctx, x.ptr), v)
+    end
+end
+HIPVector{T, N}(u::UndefInitializer, dims::Integer...; kw...) where {T, N} = HIPVector{T, N}(u, dims; kw...)
+HIPVector{T}(u::UndefInitializer, dims::Integer...; kw...) where {T} = HIPVector{T, length(dims)}(u, dims; kw...)
+Base.size(v::HIPVector) = v.dims
+Base.sizeof(v::HIPVector{T}) where T = length(v) * sizeof(T)
+Base.pointer(v::HIPVector) = v.ptr
+Base.unsafe_convert(::Type{Ptr{T}}, v::HIPVector{T}) where T = v.ptr
+Base.getindex(v::HIPVector, i...) = error("scalar indexing of a device array: copyto! a host Array first")
+# copyto! both ways (ref device_to_host!/host_to_device!, src/blocking/blocks.jl:121-143); kind: 1 H2D, 2 D2H, 3 D2D
+Base.copyto!(dst::Array{T}, src::HIPVector{T}) where T = (check(ccall(fn(:armon_hip_memcpy), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), src.dev.ctx, dst, src.ptr, sizeof(dst), 2)); dst)
+Base.copyto!(dst::HIPVector{T}, src::Array{T}) where T = (check(ccall(fn(:armon_hip_memcpy), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), dst.dev.ctx, dst.ptr, src, sizeof(src), 1)); dst)
+Base.copyto!(dst::HIPVector{T}, src::HIPVector{T}) where T = (check(ccall(fn(:armon_hip_memcpy), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), dst.dev.ctx, dst.ptr, src.ptr, sizeof(src), 3)); dst)
+
+# ---- backend hooks (ref src/parameters.jl:751-802,921-951,1031-1038) -----------------------------------------------
+function create_device(::Val{:HIP_native})
+    CURRENT_DEVICE[] = HIPNative(C_NULL, 0)           # the context is created by init_backend, once the library is known
+end
+
+function init_backend(params::ArmonParameters, dev::HIPNative;
+                      armon_hip_lib = "libarmon_hip.so", device_id = 0, fused_sweep = true, exact_arithmetic = false, options...)
+    LIB[] = Libdl.dlopen(armon_hip_lib)
+    empty!(SYMS)
+    @assert ccall(fn(:armon_hip_flt_size), Cint, ()) == 8      # ref ext/ArmonKokkos.jl:122-139
+    @assert ccall(fn(:armon_hip_idx_size), Cint, ()) == 8
+    ctx = Ref{Ptr{Cvoid}}()
+    check(ccall(fn(:armon_hip_init), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), device_id, C_NULL, ctx))
+    dev.ctx, dev.device_id = ctx[], device_id
+    params.backend_options = (; fused_sweep, exact_arithmetic)
+    return options
+end
+
+device_array_type(::HIPNative) = HIPVector            # the reference applies {T, 1} (src/blocking/block_grid.jl:52)
+host_array_type(::HIPNative) = Array
 Base.wait(params::ArmonParameters{<:Any, HIPNative}) =
-    check(ccall((:armon_hip_sync, lib[]), Cint, (Ptr{Cvoid},), params.device.ctx))
+    check(ccall(fn(:armon_hip_sync), Cint, (Ptr{Cvoid},), params.device.ctx))
 function device_memory_info(dev::HIPNative)
     free = Ref{Csize_t}(); total = Ref{Csize_t}()
-    check(ccall((:armon_hip_device_memory_info, lib[]), Cint, (Ptr{Cvoid}, Ptr{Csize_t}, Ptr{Csize_t}), dev.ctx, free, total))
+    check(ccall(fn(:armon_hip_device_memory_info), Cint, (Ptr{Cvoid}, Ptr{Csize_t}, Ptr{Csize_t}), dev.ctx, free, total))
     (total = UInt64(total[]), free = UInt64(free[]))
 end
+function print_device_info(io::IO, pad::Int, p::ArmonParameters{<:Any, HIPNative})
+    buf = zeros(UInt8, 256)
+    check(ccall(fn(:armon_hip_device_name), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t), p.device.ctx, buf, 256))
+    Armon.print_parameter(io, pad, "GPU", unsafe_string(pointer(buf)))
+end
 
-# ---- ranges: DomainRange (1-based) → armon_range (0-based), cf. ext/ArmonKokkos.jl:10-30 -------------------
+# ---- ranges: DomainRange (1-based) → armon_range (0-based), cf. ext/ArmonKokkos.jl:10-30 ---------------------------
 struct CRange; col_start::Int64; col_step::Int64; col_len::Int64; row_start::Int64; row_len::Int64; end
 CRange(r::DomainRange) = CRange(first(r.col) - 1, step(r.col), length(r.col), first(r.row) - 1, length(r.row))
-const P = Ptr{Float64}
 
-# ---- kernel main functions: one method per @generic_kernel (signatures: SURVEY §8b) -------------------------
-const HP = ArmonParameters{Float64, HIPNative}
+# ---- kernel main functions: one method per @generic_kernel (signatures: SURVEY §8b) --------------------------------
+const HP{T} = ArmonParameters{T, HIPNative}
 
-perfect_gas_EOS!(p::HP, d::BlockData, r::DomainRange, γ; kw...) = check(ccall((:armon_hip_perfect_gas_EOS, lib[]), Cint,
-    (Ptr{Cvoid}, CRange, Float64, P, P, P, P, P, P, P), p.device.ctx, CRange(r), γ, d.ρ, d.E, d.u, d.v, d.p, d.c, d.g))
+perfect_gas_EOS!(p::HP{T}, d::BlockData, r::DomainRange, γ; kw...) where T = check(ccall(fn(:armon_hip_perfect_gas_EOS, T), Cint,
+    (Ptr{Cvoid}, CRange, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
+    p.device.ctx, CRange(r), γ, d.ρ, d.E, d.u, d.v, d.p, d.c, d.g))
 
-bizarrium_EOS!(p::HP, d::BlockData, r::DomainRange; kw...) = check(ccall((:armon_hip_bizarrium_EOS, lib[]), Cint,
-    (Ptr{Cvoid}, CRange, P, P, P, P, P, P, P), p.device.ctx, CRange(r), d.ρ, d.u, d.v, d.E, d.p, d.c, d.g))
+bizarrium_EOS!(p::HP{T}, d::BlockData, r::DomainRange; kw...) where T = check(ccall(fn(:armon_hip_bizarrium_EOS, T), Cint,
+    (Ptr{Cvoid}, CRange, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
+    p.device.ctx, CRange(r), d.ρ, d.u, d.v, d.E, d.p, d.c, d.g))
 
-acoustic!(p::HP, d::BlockData, r::DomainRange, s::Int, uˢ, pˢ, uₐ; kw...) = check(ccall((:armon_hip_acoustic, lib[]), Cint,
-    (Ptr{Cvoid}, CRange, Int64, P, P, P, P, P, P), p.device.ctx, CRange(r), s, uˢ, pˢ, d.ρ, uₐ, d.p, d.c))
+acoustic!(p::HP{T}, d::BlockData, r::DomainRange, s::Int, uˢ, pˢ, uₐ; kw...) where T = check(ccall(fn(:armon_hip_acoustic, T), Cint,
+    (Ptr{Cvoid}, CRange, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
+    p.device.ctx, CRange(r), s, uˢ, pˢ, d.ρ, uₐ, d.p, d.c))
 
 limiter_tag(::Armon.NoLimiter) = Cint(0); limiter_tag(::Armon.MinmodLimiter) = Cint(1)
 limiter_tag(::Armon.SuperbeeLimiter) = Cint(2)                    # ref ext/ArmonKokkos.jl:50-57
-acoustic_GAD!(p::HP, d::BlockData, r::DomainRange, s::Int, dt, dx, uₐ, lim; kw...) = check(ccall((:armon_hip_acoustic_GAD, lib[]), Cint,
-    (Ptr{Cvoid}, CRange, Int64, Float64, Float64, P, P, P, P, P, P, Cint),
+acoustic_GAD!(p::HP{T}, d::BlockData, r::DomainRange, s::Int, dt, dx, uₐ, lim; kw...) where T = check(ccall(fn(:armon_hip_acoustic_GAD, T), Cint,
+    (Ptr{Cvoid}, CRange, Int64, T, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cint),
     p.device.ctx, CRange(r), s, dt, dx, d.uˢ, d.pˢ, d.ρ, uₐ, d.p, d.c, limiter_tag(lim)))
 
-cell_update!(p::HP, d::BlockData, r::DomainRange, s::Int, dx, dt, uₐ; kw...) = check(ccall((:armon_hip_cell_update, lib[]), Cint,
-    (Ptr{Cvoid}, CRange, Int64, Float64, Float64, P, P, P, P, P), p.device.ctx, CRange(r), s, dx, dt, d.uˢ, d.pˢ, d.ρ, uₐ, d.E))
+cell_update!(p::HP{T}, d::BlockData, r::DomainRange, s::Int, dx, dt, uₐ; kw...) where T = check(ccall(fn(:armon_hip_cell_update, T), Cint,
+    (Ptr{Cvoid}, CRange, Int64, T, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
+    p.device.ctx, CRange(r), s, dx, dt, d.uˢ, d.pˢ, d.ρ, uₐ, d.E))
 
-advection_first_order!(p::HP, d::BlockData, r::DomainRange, s::Int, dt, aρ, auρ, avρ, aEρ; kw...) = check(ccall(
-    (:armon_hip_advection_first_order, lib[]), Cint, (Ptr{Cvoid}, CRange, Int64, Float64, P, P, P, P, P, P, P, P, P),
+advection_first_order!(p::HP{T}, d::BlockData, r::DomainRange, s::Int, dt, aρ, auρ, avρ, aEρ; kw...) where T = check(ccall(
+    fn(:armon_hip_advection_first_order, T), Cint,
+    (Ptr{Cvoid}, CRange, Int64, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
     p.device.ctx, CRange(r), s, dt, d.uˢ, d.ρ, d.u, d.v, d.E, aρ, auρ, avρ, aEρ))
 
-advection_second_order!(p::HP, d::BlockData, r::DomainRange, s::Int, dx, dt, aρ, auρ, avρ, aEρ; kw...) = check(ccall(
-    (:armon_hip_advection_second_order, lib[]), Cint, (Ptr{Cvoid}, CRange, Int64, Float64, Float64, P, P, P, P, P, P, P, P, P),
+advection_second_order!(p::HP{T}, d::BlockData, r::DomainRange, s::Int, dx, dt, aρ, auρ, avρ, aEρ; kw...) where T = check(ccall(
+    fn(:armon_hip_advection_second_order, T), Cint,
+    (Ptr{Cvoid}, CRange, Int64, T, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
     p.device.ctx, CRange(r), s, dx, dt, d.uˢ, d.ρ, d.u, d.v, d.E, aρ, auρ, avρ, aEρ))
 
-euler_projection!(p::HP, d::BlockData, r::DomainRange, s::Int, dx, dt, aρ, auρ, avρ, aEρ; kw...) = check(ccall(
-    (:armon_hip_euler_projection, lib[]), Cint, (Ptr{Cvoid}, CRange, Int64, Float64, Float64, P, P, P, P, P, P, P, P, P),
+euler_projection!(p::HP{T}, d::BlockData, r::DomainRange, s::Int, dx, dt, aρ, auρ, avρ, aEρ; kw...) where T = check(ccall(
+    fn(:armon_hip_euler_projection, T), Cint,
+    (Ptr{Cvoid}, CRange, Int64, T, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
     p.device.ctx, CRange(r), s, dx, dt, d.uˢ, d.ρ, d.u, d.v, d.E, aρ, auρ, avρ, aEρ))
 
-function boundary_conditions!(p::HP, d::BlockData, r::DomainRange, bsize, axis, side, u_factor, v_factor; kw...)
-    incr = stride_along(bsize, axis); side in Armon.first_sides() && (incr = -incr)      # ref src/halo_exchange.jl:8-10
-    check(ccall((:armon_hip_boundary_conditions, lib[]), Cint, (Ptr{Cvoid}, CRange, Int64, Cint, Float64, Float64,
-        P, P, P, P, P, P, P), p.device.ctx, CRange(r), incr, ghosts(bsize), u_factor, v_factor, d.ρ, d.u, d.v, d.p, d.c, d.g, d.E))
+function boundary_conditions!(p::HP{T}, d::BlockData, r::DomainRange, bsize, axis, side, u_factor, v_factor; kw...) where T
+    incr = stride_along(bsize, axis); side in first_sides() && (incr = -incr)      # ref src/halo_exchange.jl:8-10
+    check(ccall(fn(:armon_hip_boundary_conditions, T), Cint,
+        (Ptr{Cvoid}, CRange, Int64, Cint, T, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
+        p.device.ctx, CRange(r), incr, ghosts(bsize), u_factor, v_factor, d.ρ, d.u, d.v, d.p, d.c, d.g, d.E))
 end
 
-function pack_to_array!(p::HP, r::DomainRange, bsize, side, array, vars::NTuple{N}; kw...) where N
-    ptrs = [Base.unsafe_convert(P, v) for v in vars]            # host array of N device pointers
-    check(ccall((:armon_hip_pack_to_array, lib[]), Cint, (Ptr{Cvoid}, CRange, Cint, Int64, P, Cint, Ptr{P}),
+function pack_to_array!(p::HP{T}, r::DomainRange, bsize, side, array, vars::NTuple{N}; kw...) where {T, N}
+    ptrs = Ptr{T}[Base.unsafe_convert(Ptr{T}, v) for v in vars]            # host array of N device pointers
+    GC.@preserve vars check(ccall(fn(:armon_hip_pack_to_array, T), Cint,
+        (Ptr{Cvoid}, CRange, Cint, Int64, Ptr{T}, Cint, Ptr{Ptr{T}}),
         p.device.ctx, CRange(r), ghosts(bsize), real_face_size(bsize, side), array, N, ptrs))
 end
-function unpack_from_array!(p::HP, r::DomainRange, bsize, side, array, vars::NTuple{N}; kw...) where N
-    ptrs = [Base.unsafe_convert(P, v) for v in vars]
-    check(ccall((:armon_hip_unpack_from_array, lib[]), Cint, (Ptr{Cvoid}, CRange, Cint, Int64, P, Cint, Ptr{P}),
+function unpack_from_array!(p::HP{T}, r::DomainRange, bsize, side, array, vars::NTuple{N}; kw...) where {T, N}
+    ptrs = Ptr{T}[Base.unsafe_convert(Ptr{T}, v) for v in vars]
+    GC.@preserve vars check(ccall(fn(:armon_hip_unpack_from_array, T), Cint,
+        (Ptr{Cvoid}, CRange, Cint, Int64, Ptr{T}, Cint, Ptr{Ptr{T}}),
         p.device.ctx, CRange(r), ghosts(bsize), real_face_size(bsize, side), array, N, ptrs))
 end
 
-function dtCFL_kernel(p::HP, state::SolverState, blk::LocalTaskBlock, Δx::NTuple{2})   # ref src/reductions.jl:65
-    d = block_device_data(blk); r = block_domain_range(blk.size, state.steps_ranges.real_domain); out = Ref{Float64}()
-    check(ccall((:armon_hip_dtCFL, lib[]), Cint, (Ptr{Cvoid}, CRange, Float64, Float64, P, P, P, Ptr{Float64}),
+function dtCFL_kernel(p::HP{T}, state::SolverState, blk::LocalTaskBlock, Δx::NTuple{2}) where T   # ref src/reductions.jl:65
+    d = block_device_data(blk); r = block_domain_range(blk.size, state.steps_ranges.real_domain); out = Ref{T}()
+    check(ccall(fn(:armon_hip_dtCFL, T), Cint, (Ptr{Cvoid}, CRange, T, T, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}),
         p.device.ctx, CRange(r), Δx[1], Δx[2], d.u, d.v, d.c, out))
     out[]
 end
 
-function conservation_vars(p::HP, blk::LocalTaskBlock)                                   # ref src/reductions.jl:271
+function conservation_vars(p::HP{T}, blk::LocalTaskBlock) where T                                  # ref src/reductions.jl:271
     d = block_device_data(blk); r = block_domain_range(blk.size, blk.state.steps_ranges.real_domain)
-    out = Ref{NTuple{2, Float64}}(); ds = prod(p.domain_size ./ p.global_grid)
-    check(ccall((:armon_hip_conservation_vars, lib[]), Cint, (Ptr{Cvoid}, CRange, Float64, P, P, Ptr{NTuple{2,Float64}}),
+    out = Ref{NTuple{2, T}}(); ds = T(prod(p.domain_size ./ p.global_grid))
+    check(ccall(fn(:armon_hip_conservation_vars, T), Cint, (Ptr{Cvoid}, CRange, T, Ptr{T}, Ptr{T}, Ptr{NTuple{2, T}}),
         p.device.ctx, CRange(r), ds, d.ρ, d.E, out))
     out[]
 end
+
 # init_test (ref src/kernels.jl:106-145,176-207): test tag as in ext/ArmonKokkos.jl:60-69, the 16 BlockData vectors
 # in field order (== armon_block_data), the block's global position and the cell sizes. The library zeroes uˢ,pˢ,work_*.
-struct CBlockData; x::P; y::P; ρ::P; u::P; v::P; E::P; p::P; c::P; g::P; uˢ::P; pˢ::P; w1::P; w2::P; w3::P; w4::P; mask::P; end
+struct CBlockData{T}
+    x::Ptr{T}; y::Ptr{T}; ρ::Ptr{T}; u::Ptr{T}; v::Ptr{T}; E::Ptr{T}; p::Ptr{T}; c::Ptr{T}; g::Ptr{T}
+    uˢ::Ptr{T}; pˢ::Ptr{T}; work_1::Ptr{T}; work_2::Ptr{T}; work_3::Ptr{T}; work_4::Ptr{T}; mask::Ptr{T}
+end
+CBlockData{T}(d::BlockData) where T = CBlockData{T}((Base.unsafe_convert(Ptr{T}, getfield(d, f)) for f in Armon.block_vars())...)
 test_tag(::Armon.Sod) = Cint(0); test_tag(::Armon.Sod_y) = Cint(1); test_tag(::Armon.Sod_circ) = Cint(2)
 test_tag(::Armon.Bizarrium) = Cint(3); test_tag(::Armon.Sedov) = Cint(4); test_tag(::Armon.DebugIndexes) = Cint(5)
-function init_test(p::HP, d::BlockData, r::DomainRange, global_pos, bsize, ΔX, vars_to_zero, test; kw...)
-    bd = Ref(CBlockData(d.x, d.y, d.ρ, d.u, d.v, d.E, d.p, d.c, d.g, d.uˢ, d.pˢ, d.work_1, d.work_2, d.work_3, d.work_4, d.mask))
-    gpos = Ref(NTuple{2,Int64}(global_pos)); gN = Ref(NTuple{2,Int64}(p.global_grid))
-    origin = Ref(NTuple{2,Float64}(p.origin)); dX = Ref(NTuple{2,Float64}(ΔX))
-    sz = Armon.block_size(bsize)
-    check(ccall((:armon_hip_init_test, lib[]), Cint,
-        (Ptr{Cvoid}, CRange, Cint, Int64, Int64, Cint, Ptr{NTuple{2,Int64}}, Ptr{NTuple{2,Int64}}, Ptr{NTuple{2,Float64}},
-         Ptr{NTuple{2,Float64}}, Float64, Ptr{CBlockData}),
+function init_test(p::HP{T}, d::BlockData, r::DomainRange, global_pos, bsize, ΔX, vars_to_zero, test; kw...) where T
+    bd = Ref(CBlockData{T}(d))
+    gpos = Ref(NTuple{2, Int64}(global_pos)); gN = Ref(NTuple{2, Int64}(p.global_grid))
+    origin = Ref(NTuple{2, T}(p.origin)); dX = Ref(NTuple{2, T}(ΔX))
+    sz = block_size(bsize)
+    GC.@preserve d check(ccall(fn(:armon_hip_init_test, T), Cint,
+        (Ptr{Cvoid}, CRange, Cint, Int64, Int64, Cint, Ptr{NTuple{2, Int64}}, Ptr{NTuple{2, Int64}}, Ptr{NTuple{2, T}},
+         Ptr{NTuple{2, T}}, T, Ptr{CBlockData{T}}),
         p.device.ctx, CRange(r), test_tag(test), sz[1], sz[2], ghosts(bsize), gpos, gN, origin, dX,
-        test isa Armon.Sedov ? test.r : 0.0, bd))
+        test isa Armon.Sedov ? T(test.r) : zero(T), bd))
 end
 
-# ---- fused sweep + placement of the streamed vectors (INTEGRATION.md §2) -------------------------------------
-Base.@kwdef struct SweepDesc      # == armon_sweep_desc, include/armon_hip.h
+# ---- fused sweep: `solver_cycle` on this device (INTEGRATION.md §2) ----------------------------------------------------
+# The staged overrides above make the backend a drop-in at the reference's five passes per sweep. The override below
+# replaces the sweep body of solver_cycle (ref src/solver.jl:288-320) by ONE kernel per sweep, with what surrounds it:
+# ping-pong state vectors, the dt/CFL reduction fused into the last sweep of a cycle and consumed one cycle late (the
+# reference's own lag, ref src/solver_state.jl:89-99,145-166), `p` materialised on the final cycle.
+# Precedent for overriding whole steps on a device type: ext/ArmonKokkos.jl:212-258.
+struct SweepDesc{T}      # == armon_sweep_desc / armon_sweep_desc_f32, include/armon_hip.h
     axis::Cint; scheme::Cint; limiter::Cint; projection::Cint; eos::Cint; nghost::Cint
-    bc_low::Cint; bc_high::Cint; exact::Cint = 0; x_kernel::Cint = 0
-    nx::Int64; ny::Int64; dt::Float64; dx::Float64; gamma::Float64 = 7/5
+    bc_low::Cint; bc_high::Cint; exact::Cint; x_kernel::Cint
+    nx::Int64; ny::Int64; dt::Float64; dx::Float64; gamma::Float64
     u_factor_low::Float64; v_factor_low::Float64; u_factor_high::Float64; v_factor_high::Float64
-    rho_in::P; u_in::P; v_in::P; E_in::P; rho_out::P; u_out::P; v_out::P; E_out::P
-    p_out::P = C_NULL; c_out::P = C_NULL; dt_cfl_out::P = C_NULL; cfl_dx::Float64 = 0; cfl_dy::Float64 = 0
-    out_lo::Int64 = 0; out_hi::Int64 = 0; dt_accumulate::Cint = 0; reserved::Cint = 0
+    rho_in::Ptr{T}; u_in::Ptr{T}; v_in::Ptr{T}; E_in::Ptr{T}
+    rho_out::Ptr{T}; u_out::Ptr{T}; v_out::Ptr{T}; E_out::Ptr{T}
+    p_out::Ptr{T}; c_out::Ptr{T}
+    dt_cfl_out::Ptr{T}; cfl_dx::Float64; cfl_dy::Float64
+    out_lo::Int64; out_hi::Int64; dt_accumulate::Cint; reserved::Cint
 end
-fused_sweep!(p::HP, desc::SweepDesc) =
-    check(ccall((:armon_hip_sweep, lib[]), Cint, (Ptr{Cvoid}, Ref{SweepDesc}), p.device.ctx, desc))
 
-"pool[1:4] = (ρ,u,v,E) holding the state, pool[5:8] their ping-pong partners, the rest spares → indices to keep"
-function tune_placement!(p::HP, x_desc::SweepDesc, y_desc::SweepDesc, pool::Vector{<:HIPVector}; tries = 12)
-    ptrs = [Ptr{Cvoid}(v.ptr) for v in pool]; picks = zeros(Cint, 8); times = zeros(Float64, tries)
-    check(ccall((:armon_hip_tune_placement, lib[]), Cint,
-        (Ptr{Cvoid}, Ref{SweepDesc}, Ref{SweepDesc}, Ptr{Ptr{Cvoid}}, Cint, Csize_t, Cint, Ptr{Cint}, Ptr{Float64}),
-        p.device.ctx, x_desc, y_desc, ptrs, length(pool), sizeof(eltype(pool[1])) * pool[1].n, tries, picks, times))
+scheme_tag(::Armon.RiemannGodunov) = Cint(0); scheme_tag(::Armon.RiemannGAD) = Cint(1)
+projection_tag(::Armon.EulerProjection) = Cint(0); projection_tag(::Armon.Euler2ndProjection) = Cint(1)
+eos_tag(::Armon.TestCase) = Cint(0); eos_tag(::Armon.Bizarrium) = Cint(1)
+
+"What the fused path keeps per grid besides the reference's BlockData."
+mutable struct FusedState{T}
+    alt::IdDict{Any, NTuple{4, HIPVector{T, 1}}}   # block → ping-pong partners of (ρ, u, v, E)
+    dt_dev::HIPVector{T, 1}                        # device scalar written by the fused reduction
+    dt_host::Ptr{T}                                # pinned landing zone, one slot per parity of the posting cycle
+    posted::Set{Int}                               # cycles whose CFL step is on its way to the host
+end
+const FUSED = IdDict{Any, FusedState}()
+const DT_EVENT_SLOT = 1012                         # event-pool slots 1012, 1013
+
+function fused_state(p::HP{T}, grid::BlockGrid) where T
+    get!(FUSED, grid) do
+        alt = IdDict{Any, NTuple{4, HIPVector{T, 1}}}()
+        for blk in all_blocks(grid)
+            n = length(block_device_data(blk).ρ)
+            alt[blk] = ntuple(_ -> HIPVector{T, 1}(undef, n), 4)
+        end
+        host = Ref{Ptr{Cvoid}}()
+        check(ccall(fn(:armon_hip_malloc_host), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Ptr{Cvoid}}), p.device.ctx, 2 * sizeof(T), host))
+        FusedState{T}(alt, HIPVector{T, 1}(undef, 2), Ptr{T}(host[]), Set{Int}())
+    end
+end
+
+"One directional sweep of one block as ONE launch (armon_hip_sweep), then exchange the roles of the two state sets."
+function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}; emit_p::Bool, emit_dt::Bool) where T
+    d = block_device_data(blk); alt = fs.alt[blk]
+    nx, ny = real_block_size(blk.size)
+    lo, hi = first_side(state.axis), last_side(state.axis)
+    (ufl, vfl) = boundary_condition(state.test_case, lo); (ufh, vfh) = boundary_condition(state.test_case, hi)
+    Δ = p.domain_size ./ p.global_grid
+    desc = Ref(SweepDesc{T}(
+        Int(state.axis) - 1, scheme_tag(state.riemann_scheme), limiter_tag(state.riemann_limiter),
+        projection_tag(state.projection_scheme), eos_tag(state.test_case), ghosts(blk.size),
+        !has_neighbour(p, lo), !has_neighbour(p, hi), p.backend_options.exact_arithmetic, 0,
+        nx, ny, state.dt, state.dx, specific_heat_ratio(state.test_case), ufl, vfl, ufh, vfh,
+        pointer(d.ρ), pointer(d.u), pointer(d.v), pointer(d.E),
+        pointer(alt[1]), pointer(alt[2]), pointer(alt[3]), pointer(alt[4]),
+        emit_p ? pointer(d.p) : Ptr{T}(C_NULL), Ptr{T}(C_NULL),
+        emit_dt ? pointer(fs.dt_dev) : Ptr{T}(C_NULL), Δ[1], Δ[2], 0, 0, 0, 0))
+    GC.@preserve d alt check(ccall(fn(:armon_hip_sweep, T), Cint, (Ptr{Cvoid}, Ptr{SweepDesc{T}}), p.device.ctx, desc))
+    # ping-pong: the fresh state lives in `alt`; BlockData is immutable but HIPVector is ours — swap the allocations
+    for (v, a) in zip((d.ρ, d.u, d.v, d.E), alt)
+        v.ptr, a.ptr = a.ptr, v.ptr
+    end
+end
+
+function solver_cycle(p::HP{T}, grid::BlockGrid) where T
+    # per-step dumps/comparisons need the intermediate arrays of the staged kernels; MPI runs keep the reference's
+    # exchange between the staged kernels (the fused multi-GPU path is armon_hip_mgpu_* / halo_exchange, INTEGRATION §3)
+    if !p.backend_options.fused_sweep || p.compare || p.use_MPI
+        return invoke(solver_cycle, Tuple{ArmonParameters, BlockGrid}, p, grid)
+    end
+    state = first_state(grid)
+    gdt = state.global_dt
+    fs = fused_state(p, grid)
+    if gdt.cycle == 0
+        update_EOS!(p, state, grid)                       # c of the initial state, for the first time step only
+        next_time_step(p, state, grid) && return true     # staged dtCFL kernel, synchronous, once per run
+    else
+        state.dt = gdt.current_dt                         # known since the previous cycle (one-cycle lag)
+    end
+    will_end = gdt.cycle + 1 ≥ p.maxcycle || gdt.time + gdt.current_dt ≥ p.maxtime    # time_loop's exit test (src/solver.jl:350)
+    sweeps = collect(split_axes(state))
+    for (k, (axis, dt_factor)) in enumerate(sweeps)
+        update_solver_state!(p, state, axis, dt_factor)
+        last = k == length(sweeps)
+        for blk in all_blocks(grid)                       # one block per GPU (use_cache_blocking=false)
+            fused_sweep!(p, state, blk, fs; emit_p = last && will_end, emit_dt = last && !p.cst_dt)
+        end
+    end
+    p.cst_dt && return false
+    # post the read-back of the CFL step this cycle's last sweep reduced (the state the NEXT cycle starts from) …
+    slot = gdt.cycle & 1
+    check(ccall(fn(:armon_hip_memcpy_async), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint),
+        p.device.ctx, fs.dt_host + slot * sizeof(T), pointer(fs.dt_dev), sizeof(T), 2))
+    check(ccall(fn(:armon_hip_event_record), Cint, (Ptr{Cvoid}, Cint), p.device.ctx, DT_EVENT_SLOT + slot))
+    push!(fs.posted, gdt.cycle)
+    # … and pick up the one the previous cycle posted: it is this cycle's `local_time_step` (ref src/reductions.jl:
+    # 164-199), contributed exactly as next_time_step would, so next_cycle! finds the state machine where it expects it.
+    if gdt.cycle > 0
+        prev = gdt.cycle - 1
+        check(ccall(fn(:armon_hip_event_sync), Cint, (Ptr{Cvoid}, Cint), p.device.ctx, DT_EVENT_SLOT + (prev & 1)))
+        delete!(fs.posted, prev)
+        contribute_to_dt!(p, gdt, unsafe_load(fs.dt_host, (prev & 1) + 1); all_blocks = true)
+    end
+    return false
+end
+
+# ---- placement of the streamed vectors (DESIGN §3) -----------------------------------------------------------------------
+"pool[1:4] = (ρ,u,v,E) holding the state, pool[5:8] their ping-pong partners, the rest spares → 1-based indices to keep"
+function tune_placement!(p::HP{T}, x_desc::SweepDesc{T}, y_desc::SweepDesc{T}, pool::Vector{<:HIPVector{T}}; tries = 12) where T
+    ptrs = Ptr{Cvoid}[Ptr{Cvoid}(v.ptr) for v in pool]; picks = zeros(Cint, 8); times = zeros(Float64, tries)
+    GC.@preserve pool check(ccall(fn(:armon_hip_tune_placement, T), Cint,
+        (Ptr{Cvoid}, Ptr{SweepDesc{T}}, Ptr{SweepDesc{T}}, Ptr{Ptr{Cvoid}}, Cint, Csize_t, Cint, Ptr{Cint}, Ptr{Float64}),
+        p.device.ctx, Ref(x_desc), Ref(y_desc), ptrs, length(pool), sizeof(pool[1]), tries, picks, times))
     picks .+ 1, times
 end
+
+# ---- multi-GPU without MPI: every tile in this process (INTEGRATION.md §3) ------------------------------------------------
+struct HaloDesc      # == armon_halo_desc
+    nx::Int64; ny::Int64; nghost::Cint; nvars::Cint
+    vars::NTuple{8, Ptr{Cvoid}}
+end
+HaloDesc(nx, ny, g, vars) = HaloDesc(nx, ny, g, length(vars),
+    ntuple(i -> i ≤ length(vars) ? Ptr{Cvoid}(pointer(vars[i])) : C_NULL, 8))
+
+mutable struct TileGroup; handle::Ptr{Cvoid}; px::Int; py::Int; end
+function TileGroup(px, py, device_ids::Vector{Cint})
+    g = Ref{Ptr{Cvoid}}()
+    check(ccall(fn(:armon_hip_mgpu_init), Cint, (Cint, Cint, Ptr{Cint}, Ptr{Ptr{Cvoid}}), px, py, device_ids, g))
+    finalizer(x -> ccall(fn(:armon_hip_mgpu_destroy), Cint, (Ptr{Cvoid},), x.handle), TileGroup(g[], px, py))
+end
+"One process per GPU under MPI: `id` = the bytes of armon_hip_mgpu_unique_id from rank 0 after MPI.Bcast!."
+function TileGroup(px, py, rank, device_id, id::Vector{UInt8})
+    g = Ref{Ptr{Cvoid}}()
+    check(ccall(fn(:armon_hip_mgpu_init_rank), Cint, (Cint, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
+        px, py, rank, device_id, C_NULL, id, g))
+    finalizer(x -> ccall(fn(:armon_hip_mgpu_destroy), Cint, (Ptr{Cvoid},), x.handle), TileGroup(g[], px, py))
+end
+unique_id() = (id = zeros(UInt8, 256); check(ccall(fn(:armon_hip_mgpu_unique_id), Cint, (Ptr{Cvoid},), id)); id)
+tile_context(g::TileGroup, k) = ccall(fn(:armon_hip_mgpu_ctx), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), g.handle, k)
+halo_exchange_start!(g::TileGroup, axis, tiles::Vector{HaloDesc}, ::Type{T} = Float64) where T =
+    check(ccall(fn(:armon_hip_halo_exchange_start, T), Cint, (Ptr{Cvoid}, Cint, Ptr{HaloDesc}), g.handle, Int(axis) - 1, tiles))
+halo_exchange_finish!(g::TileGroup, axis, tiles::Vector{HaloDesc}, ::Type{T} = Float64) where T =
+    check(ccall(fn(:armon_hip_halo_exchange_finish, T), Cint, (Ptr{Cvoid}, Cint, Ptr{HaloDesc}), g.handle, Int(axis) - 1, tiles))
+dt_allreduce!(g::TileGroup, dt_dev::Vector{Ptr{T}}) where T =
+    check(ccall(fn(:armon_hip_dt_allreduce, T), Cint, (Ptr{Cvoid}, Ptr{Ptr{T}}), g.handle, dt_dev))
 
 end # module

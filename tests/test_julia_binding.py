@@ -1,0 +1,179 @@
+"""The reference-side binding (integration/ArmonHIPNative.jl) cannot be executed here (no `julia`), so what can be
+checked statically is: every `ccall(fn(:armon_hip_…[, T]), ret, (argtypes…), args…)` in it is parsed and compared with
+the C ABI as bound by armon.jl_amd/_lib.py (SIGNATURES = include/armon_hip.h, itself checked against the library's
+exports by test_host_logic.py) — symbol exists, arity, the C class and width of every argument and of the return type,
+number of values actually passed — for the fp64 symbol and, where the call is generic in T, the `_f32` one; and the
+Julia mirrors of the C structs (CRange, CBlockData, SweepDesc, HaloDesc) against the ctypes structures field by field.
+"""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from armon_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = open(os.path.join(ROOT, "integration", "ArmonHIPNative.jl"), encoding="utf-8").read()
+CODE = "\n".join(line.split("#", 1)[0] if not line.lstrip().startswith('"') else line for line in JL.splitlines())
+
+
+def split_top(s):
+    """Split on top-level commas (parentheses, braces and brackets nest)."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def matching(s, i):
+    """Index of the parenthesis closing the one at s[i]."""
+    depth = 0
+    for k in range(i, len(s)):
+        if s[k] in "({[":
+            depth += 1
+        elif s[k] in ")}]":
+            depth -= 1
+            if depth == 0:
+                return k
+    raise ValueError("unbalanced")
+
+
+def ccalls():
+    found = []
+    for m in re.finditer(r"ccall\(\s*fn\(:(armon_hip_\w+)(\s*,\s*T)?\)", CODE):
+        start = CODE.index("(", m.start())
+        body = CODE[start + 1:matching(CODE, start)]
+        parts = split_top(body)
+        ret, argtypes, args = parts[1], parts[2], parts[3:]
+        assert argtypes.startswith("(") and argtypes.endswith(")"), (m.group(1), argtypes)
+        types = split_top(argtypes[1:-1])
+        found.append((m.group(1), bool(m.group(2)), ret, types, args))
+    return found
+
+
+def jl_kind(t, real_width):
+    t = t.strip()
+    if t in ("Cint", "Int32"):
+        return ("int", 4)
+    if t == "Int64":
+        return ("int", 8)
+    if t == "Csize_t":
+        return ("int", 8)
+    if t == "Float64":
+        return ("float", 8)
+    if t == "T":
+        return ("float", real_width)
+    if t == "CRange":
+        return ("struct", C.sizeof(_lib.Range))
+    if t == "Cstring" or t.startswith("Ptr{") or t.startswith("Ref{"):
+        return ("ptr", 8)
+    raise AssertionError(f"unmapped Julia type {t!r}")
+
+
+def c_kind(t):
+    if t is None:
+        return ("void", 0)
+    if t in (C.c_int, C.c_int32):
+        return ("int", 4)
+    if t in (C.c_int64, C.c_size_t):
+        return ("int", 8)
+    if t is C.c_double:
+        return ("float", 8)
+    if t is C.c_float:
+        return ("float", 4)
+    if t in (C.c_void_p, C.c_char_p) or isinstance(t, type(C.POINTER(C.c_int))) and issubclass(t, C._Pointer):
+        return ("ptr", 8)
+    if isinstance(t, type) and issubclass(t, C.Structure):
+        return ("struct", C.sizeof(t))
+    raise AssertionError(f"unmapped ctypes type {t!r}")
+
+
+CALLS = ccalls()
+
+
+def test_the_binding_calls_the_abi_it_claims():
+    names = {c[0] for c in CALLS}
+    assert len(CALLS) >= 35
+    # the 1:1 kernels, the hooks, the fused sweep and the multi-GPU entry points are all bound
+    for must in ("perfect_gas_EOS", "bizarrium_EOS", "acoustic", "acoustic_GAD", "cell_update", "advection_first_order",
+                 "advection_second_order", "euler_projection", "boundary_conditions", "pack_to_array", "unpack_from_array",
+                 "dtCFL", "conservation_vars", "init_test", "sweep", "tune_placement", "init", "sync", "malloc", "free",
+                 "memcpy", "memcpy_async", "malloc_host", "event_record", "event_sync", "device_memory_info",
+                 "mgpu_init", "mgpu_init_rank", "mgpu_unique_id", "halo_exchange_start", "halo_exchange_finish",
+                 "dt_allreduce"):
+        assert "armon_hip_" + must in names, must
+
+
+@pytest.mark.parametrize("call", CALLS, ids=[f"{c[0]}{'<T>' if c[1] else ''}#{i}" for i, c in enumerate(CALLS)])
+def test_ccall_matches_the_header(call):
+    name, generic, ret, types, args = call
+    variants = [(name, 8)] + ([(name + "_f32", 4)] if generic else [])
+    for sym, width in variants:
+        assert sym in _lib.SIGNATURES, f"{sym} is not declared in include/armon_hip.h"
+        res, argtypes = _lib.SIGNATURES[sym]
+        assert len(types) == len(argtypes), f"{sym}: {len(types)} argument types in the ccall, {len(argtypes)} in the header"
+        assert len(args) == len(types), f"{sym}: {len(args)} values passed for {len(types)} declared types"
+        assert jl_kind(ret, width) == c_kind(res), f"{sym}: return type {ret}"
+        for k, (jt, ct) in enumerate(zip(types, argtypes)):
+            assert jl_kind(jt, width) == c_kind(ct), f"{sym}: argument {k} is {jt} in the ccall, {ct} in the header"
+
+
+def jl_struct(name):
+    m = re.search(r"struct\s+" + name + r"(\{T\})?\s*[;\n](.*?)\bend\b", CODE, re.S)
+    assert m, name
+    fields = []
+    for f in re.split(r"[;\n]", m.group(2)):
+        f = f.strip()
+        if "::" in f:
+            n, t = f.split("::", 1)
+            fields.append((n.strip(), t.strip()))
+    return fields
+
+
+def field_kind(t, width):
+    m = re.fullmatch(r"NTuple\{(\d+),\s*(.+)\}", t)
+    if m:
+        return ("array", int(m.group(1))) + jl_kind(m.group(2), width)
+    return jl_kind(t, width)
+
+
+def ct_field_kind(t):
+    if isinstance(t, type) and issubclass(t, C.Array):
+        return ("array", t._length_) + c_kind(t._type_)
+    return c_kind(t)
+
+
+@pytest.mark.parametrize("jl,ct,same_names", [("CRange", _lib.Range, True), ("SweepDesc", _lib.SweepDesc, True),
+                                              ("HaloDesc", _lib.HaloDesc, True), ("CBlockData", _lib.BlockDataPtrs, False)])
+def test_struct_mirrors(jl, ct, same_names):
+    fields = jl_struct(jl)
+    assert len(fields) == len(ct._fields_), (jl, len(fields), len(ct._fields_))
+    for (jn, jt), (cn, ctt) in zip(fields, ct._fields_):
+        if same_names:
+            assert jn == cn, (jl, jn, cn)
+        assert field_kind(jt, 8) == ct_field_kind(ctt), (jl, jn, jt, ctt)
+
+
+def test_device_array_type_and_fused_override_are_what_the_reference_needs():
+    # ref src/blocking/block_grid.jl:52-53 applies {T, 1} to device_array_type(dev): element type AND rank parameters
+    assert re.search(r"mutable struct HIPVector\{T,\s*N\}\s*<:\s*AbstractArray\{T,\s*N\}", CODE)
+    assert re.search(r"HIPVector\{T,\s*N\}\(::UndefInitializer,\s*dims::NTuple\{N,\s*Integer\}", CODE)
+    assert "device_array_type(::HIPNative) = HIPVector" in CODE
+    # the fused path is bound as a solver_cycle method on this device (precedent: ext/ArmonKokkos.jl:212-258)
+    assert re.search(r"function solver_cycle\(p::HP\{T\},\s*grid::BlockGrid\)", CODE)
+    body = CODE[CODE.index("function solver_cycle(p::HP{T}"):]
+    for needle in ("fused_sweep!", "contribute_to_dt!", "emit_p = last && will_end", "armon_hip_memcpy_async",
+                   "armon_hip_event_sync", "invoke(solver_cycle"):
+        assert needle in body, needle
+    assert "v.ptr, a.ptr = a.ptr, v.ptr" in CODE        # ping-pong swap of the allocations behind BlockData's vectors
