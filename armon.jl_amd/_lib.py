@@ -82,6 +82,7 @@ SIGNATURES = {
     "armon_hip_device_memory_info": (_ci, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "armon_hip_device_name": (_ci, [_vp, C.c_char_p, C.c_size_t]),
     "armon_hip_stream": (_vp, [_vp]),
+    "armon_hip_set_tuning": (_ci, [_vp, C.c_char_p, _ci]),
     "armon_hip_malloc": (_ci, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "armon_hip_free": (_ci, [_vp, _vp]),
     "armon_hip_memcpy": (_ci, [_vp, _vp, _vp, C.c_size_t, _ci]),
@@ -115,6 +116,8 @@ SIGNATURES = {
     "armon_hip_sweep": (_ci, [_vp, C.POINTER(SweepDesc)]),
     "armon_hip_tune_placement": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc), C.POINTER(_vp), _ci,
                                        C.c_size_t, _ci, C.POINTER(_ci * 8), C.POINTER(_dbl)]),
+    "armon_hip_choose_placement": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc), C.POINTER(_vp), _ci,
+                                         C.c_size_t, _ci, _dbl, C.POINTER(_ci * 8), C.POINTER(_dbl), C.POINTER(_ci)]),
     "armon_hip_mgpu_init": (_ci, [_ci, _ci, C.POINTER(_ci), C.POINTER(_vp)]),
     "armon_hip_mgpu_unique_id": (_ci, [_vp]),
     "armon_hip_mgpu_init_rank": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, C.POINTER(_vp)]),
@@ -153,6 +156,7 @@ def _add_f32_signatures():
         SIGNATURES["armon_hip_" + name + "_f32"] = SIGNATURES["armon_hip_" + name]
     SIGNATURES["armon_hip_sweep_f32"] = SIGNATURES["armon_hip_sweep"]
     SIGNATURES["armon_hip_tune_placement_f32"] = SIGNATURES["armon_hip_tune_placement"]
+    SIGNATURES["armon_hip_choose_placement_f32"] = SIGNATURES["armon_hip_choose_placement"]
 
 
 _add_f32_signatures()

@@ -23,6 +23,15 @@ struct armon_ctx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t* ev_pool = nullptr;   // [ARMON_HIP_MAX_EVENTS], created on first use
     int n_cu = 256;
+    // Tuning knobs of the fused sweeps, read from the environment ONCE (armon_hip_init) or set with
+    // armon_hip_set_tuning (A/B tools): nothing on the launch path looks at the environment.
+    int tune_xs_niter = 0;           // ARMON_XS_NITER: strips per wave of the X sweep (0 = built-in)
+    int tune_y_seg = 0;              // ARMON_Y_SEG: rows per run of the Y march (0 = y_run_length's choice)
+    int tune_align = 1;              // ARMON_SWEEP_ALIGN: 0 = unaligned block / strip origins
+    int tune_y_cols1 = 0;            // ARMON_Y_COLS1: fp32 Y march with one column per lane
+    // y_run_length's last answer (it depends on the shape only)
+    int64_t seg_nx = -1, seg_ny = -1;
+    int seg_lag = -1, seg_value = 0;
 };
 
 namespace armon {

@@ -5,6 +5,8 @@
 // device_memory_info (ref src/parameters.jl:921-926, ext/ArmonAMDGPU.jl:25-27).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace armon {
 
 static thread_local char g_error[512] = "";
@@ -92,7 +94,22 @@ int armon_hip_init(int device_id, void* stream, armon_ctx** out)
     }
     int rc = ensure_partials(ctx, 8192);
     if (rc != ARMON_OK) { armon_hip_destroy(ctx); return rc; }
+    for (const char* knob : {"ARMON_XS_NITER", "ARMON_Y_SEG", "ARMON_SWEEP_ALIGN", "ARMON_Y_COLS1"}) {
+        const char* v = getenv(knob);
+        if (v && *v) (void)armon_hip_set_tuning(ctx, knob, atoi(v));
+    }
     *out = ctx;
+    return ARMON_OK;
+}
+
+int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value)
+{
+    ARMON_REQUIRE(ctx && knob, "NULL argument");
+    if (!strcmp(knob, "ARMON_XS_NITER")) ctx->tune_xs_niter = value > 0 ? value : 0;
+    else if (!strcmp(knob, "ARMON_Y_SEG")) ctx->tune_y_seg = value > 0 ? value : 0;
+    else if (!strcmp(knob, "ARMON_SWEEP_ALIGN")) ctx->tune_align = value < 0 ? 1 : (value != 0);
+    else if (!strcmp(knob, "ARMON_Y_COLS1")) ctx->tune_y_cols1 = value > 0;
+    else ARMON_REQUIRE(false, "unknown tuning knob '%s'", knob);
     return ARMON_OK;
 }
 

@@ -3,4 +3,5 @@
 #define ARMON_SWEEP_FN armon_hip_sweep_f32
 #define ARMON_SWEEP_DESC armon_sweep_desc_f32
 #define ARMON_TUNE_FN armon_hip_tune_placement_f32
+#define ARMON_CHOOSE_FN armon_hip_choose_placement_f32
 #include "fused_sweep_impl.hpp"

@@ -16,8 +16,9 @@
 //    pipeline as the Y sweep.
 // Redundant work is confined to the LAG (≤4) cells at both ends of a run / strip. Block and strip origins are
 // aligned to the 64-B sectors of the ghosted rows, stores are non-temporal (DESIGN.md §4.2 has the A/B numbers).
-// Tuning knobs read per launch, for tools/ab_sweep.py and the parity tests: ARMON_SWEEP_ALIGN, ARMON_XS_NITER,
-// ARMON_Y_SEG, ARMON_Y_COLS1; compile-time: ARMON_NT, ARMON_Y_PF, ARMON_Y_WAVES, ARMON_PROBE_NOCOMPUTE.
+// Tuning knobs (tools/ab_sweep.py, parity tests), read from the environment once per context or set with
+// armon_hip_set_tuning: ARMON_SWEEP_ALIGN, ARMON_XS_NITER, ARMON_Y_SEG, ARMON_Y_COLS1; compile-time: ARMON_NT,
+// ARMON_Y_PF, ARMON_Y_WAVES, ARMON_Y_BLOCK, ARMON_PROBE_NOCOMPUTE, ARMON_ONLY_HEADLINE.
 #pragma once
 #include "common.hpp"
 #include "reduce.hpp"
@@ -736,7 +737,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     if constexpr (std::is_same<real, float>::value && !PIPE::kExact) {
         // fp32, tuned arithmetic: two columns per lane when every row is 8-B aligned (even pitch and ghost width).
         // (Not instantiated for the exact flavour: build time; the tests require it to equal the one-column kernel.)
-        if (axis == ARMON_AXIS_Y && a.nx % 2 == 0 && a.g % 2 == 0 && a.nx >= 2 && !getenv("ARMON_Y_COLS1")) {
+        if (axis == ARMON_AXIS_Y && a.nx % 2 == 0 && a.g % 2 == 0 && a.nx >= 2 && !ctx->tune_y_cols1) {
             dim3 grid((unsigned)((a.nx + a.xshift + 2 * kYBlock - 1) / (2 * kYBlock)), (unsigned)((n_out + a.seg - 1) / a.seg));
             *n_blocks = (int64_t)grid.x * grid.y;
             hipLaunchKernelGGL((k_sweep_y2<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
@@ -758,9 +759,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         return check_launch("sweep_x_lds");
     }
 #endif
-    const char* niter_s = getenv("ARMON_XS_NITER");                  // tuning knob, read per launch (A/B runs)
-    const int niter_env = niter_s ? atoi(niter_s) : 0;
-    const int niter = niter_env > 0 ? niter_env : kXSNiter;
+    const int niter = ctx->tune_xs_niter > 0 ? ctx->tune_xs_niter : kXSNiter;
     const bool k1 = a.x_kernel == 3;
     const int halo = k1 ? PIPE::LAG : 4;
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
@@ -906,9 +905,19 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.E_out = d->E_out;
     a.p_out = d->p_out;
     a.c_out = d->c_out;
-    const char* seg_s = getenv("ARMON_Y_SEG");                       // tuning knob, read per launch (A/B runs)
-    const int seg_y_env = seg_s ? atoi(seg_s) : 0;
-    a.seg = X ? 512 : (seg_y_env > 0 ? seg_y_env : y_run_length(ctx->n_cu, d->nx, n_axis, lag));
+    if (X) {
+        a.seg = 512;
+    } else if (ctx->tune_y_seg > 0) {
+        a.seg = ctx->tune_y_seg;
+    } else {
+        if (ctx->seg_nx != d->nx || ctx->seg_ny != n_axis || ctx->seg_lag != lag) {
+            ctx->seg_value = y_run_length(ctx->n_cu, d->nx, n_axis, lag);
+            ctx->seg_nx = d->nx;
+            ctx->seg_ny = n_axis;
+            ctx->seg_lag = lag;
+        }
+        a.seg = ctx->seg_value;
+    }
     // the Y march addresses a run of rows with 32-bit byte offsets from the run's first row
     ARMON_REQUIRE(X || a.row_len * (int64_t)sizeof(real) * (a.seg + 2 * lag + 16) < (1ll << 32),
                   "block too wide for 32-bit row offsets (%lld cells per row, runs of %d rows)", (long long)d->nx, a.seg);
@@ -921,8 +930,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
         a.o_lo = d->out_lo;
         a.o_hi = d->out_hi;
     }
-    const char* align_s = getenv("ARMON_SWEEP_ALIGN");               // tuning knob: "0" = unaligned origins (A/B runs)
-    const bool align = !(align_s && align_s[0] == '0');
+    const bool align = ctx->tune_align != 0;
     a.xshift = (X || !align) ? 0 : d->nghost % 16;
     a.x_first = X ? (align ? a.o_lo - (a.o_lo + d->nghost) % 8 : a.o_lo) : 0;
     a.partials = nullptr;
@@ -1040,6 +1048,86 @@ extern "C" int ARMON_TUNE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, con
 #undef TUNE_TRY
     for (int k = 0; k < 8; k++) picks[k] = best[k];
     parked = false;                   // the state now lives in pool[picks[0..3]]
+    cleanup();
+    return ARMON_OK;
+}
+
+// Same choice for a pool that holds NO state worth keeping (a host calls it BEFORE init_test writes the initial
+// condition): nothing is parked or restored, so the only transient memory is the caller's spare vectors. Each
+// candidate's four input vectors are filled with a uniform state (the sweeps' instruction stream does not depend on the
+// data) and timed like above; the search stops as soon as two draws lie within `tolerance` of the best one seen (the
+// good placements form a plateau), after at most `tries` draws.
+namespace {
+__global__ void __launch_bounds__(256) k_fill_uniform(real* __restrict__ p, size_t n, real value)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+}  // namespace
+
+extern "C" int ARMON_CHOOSE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, const ARMON_SWEEP_DESC* y_desc,
+                               void* const* pool, int n_pool, size_t bytes, int tries, double tolerance, int* picks,
+                               double* times_ms, int* tries_done)
+{
+    ARMON_REQUIRE(ctx && x_desc && y_desc && pool && picks, "NULL argument");
+    ARMON_REQUIRE(n_pool >= 8 && tries >= 1 && bytes >= sizeof(real), "need at least 8 vectors and 1 try (n_pool = %d, tries = %d)", n_pool, tries);
+    for (int k = 0; k < n_pool; k++) ARMON_REQUIRE(pool[k], "pool[%d] is NULL", k);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define CHOOSE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail_hip(e_, #expr); } } while (0)
+    CHOOSE_TRY(hipEventCreate(&e0));
+    CHOOSE_TRY(hipEventCreate(&e1));
+    std::vector<int> idx(n_pool), best(8);
+    std::vector<double> seen;
+    double best_ms = 1e300;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    const size_t n = bytes / sizeof(real);
+    const real uniform[4] = {real(1), real(0), real(0), real(2.5)};          // rho, u, v, E: Sod's left state
+    int t = 0;
+    for (; t < tries; t++) {
+        for (int k = 0; k < n_pool; k++) idx[k] = k;
+        if (t > 0)
+            for (int k = 0; k < 8; k++) {                         // partial Fisher-Yates: 8 distinct vectors
+                rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+                std::swap(idx[k], idx[k + (int)(rng % (uint64_t)(n_pool - k))]);
+            }
+        ARMON_SWEEP_DESC dx = *x_desc, dy = *y_desc;
+        using ptr_t = decltype(dx.rho_out);
+        auto P = [&](int role) { return static_cast<ptr_t>(pool[idx[role]]); };
+        for (int k = 0; k < 4; k++)
+            hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P(k), n, uniform[k]);
+        dx.rho_in = P(0); dx.u_in = P(1); dx.v_in = P(2); dx.E_in = P(3);
+        dx.rho_out = P(4); dx.u_out = P(5); dx.v_out = P(6); dx.E_out = P(7);
+        dy.rho_in = P(4); dy.u_in = P(5); dy.v_in = P(6); dy.E_in = P(7);
+        dy.rho_out = P(0); dy.u_out = P(1); dy.v_out = P(2); dy.E_out = P(3);
+        double ms_min = 1e300;
+        for (int rep = 0; rep < 3; rep++) {
+            CHOOSE_TRY(hipEventRecord(e0, ctx->stream));
+            int rc = ARMON_SWEEP_FN(ctx, &dx);
+            if (rc == ARMON_OK) rc = ARMON_SWEEP_FN(ctx, &dy);
+            if (rc != ARMON_OK) { cleanup(); return rc; }
+            CHOOSE_TRY(hipEventRecord(e1, ctx->stream));
+            CHOOSE_TRY(hipEventSynchronize(e1));
+            float ms = 0.f;
+            CHOOSE_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < ms_min) ms_min = ms;
+        }
+        if (times_ms) times_ms[t] = ms_min;
+        seen.push_back(ms_min);
+        if (ms_min < best_ms) {
+            best_ms = ms_min;
+            for (int k = 0; k < 8; k++) best[k] = idx[k];
+        }
+        int near = 0;
+        for (double v : seen) near += v <= best_ms * (1. + tolerance);
+        if (tolerance > 0 && near >= 2 && t >= 1) { t++; break; }
+    }
+#undef CHOOSE_TRY
+    for (int k = 0; k < 8; k++) picks[k] = best[k];
+    if (tries_done) *tries_done = t;
     cleanup();
     return ARMON_OK;
 }

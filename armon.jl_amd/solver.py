@@ -140,7 +140,7 @@ class BlockGrid:
         for f in STATE_VARS:
             self.data[f], self.alt[f] = self.alt[f], self.data[f]
 
-    def tune_placement(self, min_bytes=256 << 20, spare=8):
+    def tune_placement(self, min_bytes=None, spare=None, keep_state=True):
         """Pick a good PHYSICAL placement for the 8 vectors a fused sweep streams (4 read + 4 written).
 
         On MI355X the same kernels on the same virtual layout run 10-20 % apart depending on where the 8
@@ -148,19 +148,28 @@ class BlockGrid:
         physical spacing, and for many spacings the 8 streams then keep meeting on the same channels/banks
         (tools/probes/probe_skew.hip, probe_pairs.hip: 2.93-3.77 ms for the same copy as a function of the
         spacing; random picks of 8 among 24 such vectors: 75 % at 2.71-2.79 ms, the back-to-back groups 2.94-3.08).
-        Nothing visible from user space predicts it, so it is measured (natively: ``armon_hip_tune_placement``):
-        ``spare`` extra vectors are allocated, ``placement_tries`` assignments of the 8 roles to vectors of the pool
-        are timed with one X and one Y sweep of the real state (the first one being the back-to-back assignment),
-        the fastest is kept and the unused vectors are freed. Called by ``init_test``; ~20 ms per try, outside any
-        timed region.
+        Nothing visible from user space predicts it, so it is measured, natively: ``spare`` extra vectors are
+        allocated, up to ``placement_tries`` assignments of the 8 roles to vectors of the pool are timed with one X
+        and one Y sweep (the first one being the back-to-back assignment), the fastest is kept and the unused
+        vectors are freed.
+
+        ``keep_state=False`` (what ``init_test`` does, BEFORE it writes the initial condition):
+        ``armon_hip_choose_placement`` — the vectors hold nothing yet, candidates are timed on a uniform state, the
+        search stops once two draws lie within 1 % of the best; transient memory = the ``spare`` (default 4) vectors
+        only, 8.6 GB at 16384². ``keep_state=True``: ``armon_hip_tune_placement`` moves a LIVE state around (4 more
+        vectors park it meanwhile; default 8 spares). ~20 ms per try, outside any timed region.
         Returns the report also stored in ``self.placement``."""
         params, dev = self.params, self.params.device
         tries = getattr(params, "placement_tries", 0)
         nbytes = self.data["rho"].nbytes
+        if min_bytes is None:
+            min_bytes = getattr(params, "placement_min_bytes", 256 << 20)
+        if spare is None:
+            spare = 8 if keep_state else 4
         if self.alt is None or tries <= 1 or nbytes < min_bytes:
             return None
         free, _total = dev.memory_info()
-        spare = int(min(spare, (free * 0.8) // nbytes - 4))      # 4 more vectors park the state meanwhile
+        spare = int(min(spare, (free * 0.8) // max(nbytes, 1) - (4 if keep_state else 0)))
         if spare < 1:
             return None
         dx = params.cell_size(0)
@@ -177,15 +186,19 @@ class BlockGrid:
         d_x = sweep_desc(params, self, Axis.X, dt, dx)
         d_y = sweep_desc(params, self, Axis.Y, dt, params.cell_size(1), emit_dt=True)     # as in a cycle
         ptrs = (C.c_void_p * len(pool))(*[v.ptr for v in pool])
-        picks, times = (C.c_int * 8)(), (C.c_double * tries)()
+        picks, times, done = (C.c_int * 8)(), (C.c_double * tries)(), C.c_int(tries)
         try:
-            check(params.fn("tune_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes, tries,
-                                              C.byref(picks), times))
+            if keep_state:
+                check(params.fn("tune_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes, tries,
+                                                  C.byref(picks), times))
+            else:
+                check(params.fn("choose_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes, tries,
+                                                    0.01, C.byref(picks), times, C.byref(done)))
         except _lib.SolverException:          # e.g. no room for the 4 transient vectors: nothing was moved
             for v in pool[8:]:
                 v.free()
             return None
-        picks, times = list(picks), list(times)
+        picks, times = list(picks), list(times)[:done.value]
         for k, f in enumerate(STATE_VARS):
             self.data[f], self.alt[f] = pool[picks[k]], pool[picks[4 + k]]
         keep = set(picks)
@@ -193,8 +206,9 @@ class BlockGrid:
             if i not in keep:
                 v.free()
         k = times.index(min(times))
-        self.placement = {"tries": tries, "pool": len(pool),
-                          "x_plus_y_ms": [round(t, 3) for t in times], "chosen": k}
+        self.placement = {"tries": len(times), "max_tries": tries, "pool": len(pool),
+                          "x_plus_y_ms": [round(t, 3) for t in times], "chosen": k, "chosen_ms": round(times[k], 3),
+                          "transient_GB": round((spare + (4 if keep_state else 0)) * nbytes / 1e9, 2)}
         return self.placement
 
     def device_to_host(self, names=MAIN_VARS):
@@ -247,7 +261,10 @@ def _range(params, corners):
 
 
 def init_test(params, grid, tune=True):
-    """ref src/kernels.jl:176-207 (+ the measured choice of the HBM placement, ``tune=False`` to skip it)"""
+    """ref src/kernels.jl:176-207 (+ the measured choice of the HBM placement of the state vectors, made BEFORE they
+    are written; ``tune=False`` to skip it, e.g. when re-initialising a grid that has been placed already)"""
+    if tune and grid.placement is None:
+        grid.tune_placement(keep_state=False)
     bs = params.block_size
     full = params.steps_ranges[Axis.X].full_domain
     gpos = (C.c_int64 * 2)(params.N_origin[0] - 1, params.N_origin[1] - 1)
@@ -259,8 +276,6 @@ def init_test(params, grid, tune=True):
     check(params.fn("init_test")(params.device.ctx, _range(params, full), params.test.tag,
                                    bs.size[0], bs.size[1], bs.ghosts, C.byref(gpos), C.byref(gN),
                                    C.byref(origin), C.byref(dX), params.test.r, C.byref(bd)))
-    if tune:
-        grid.tune_placement()
 
 
 def update_EOS(params, grid, axis=Axis.X):

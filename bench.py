@@ -323,6 +323,12 @@ def main():
             ms.append(params.device.event_elapsed_ms(1000, 1001))
         copy_gbps = 8 * nb / (sorted(ms[2:])[len(ms[2:]) // 2] * 1e-3) / 1e9
 
+    placement = grid.placement
+    if dist is not None:                      # every rank draws its own placement: report them all (the slowest sets the pace)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, grid.placement)
+        placement = [dict(rank=r, **(g or {"tries": 0})) for r, g in enumerate(gathered)]
+
     cells_local = params.N[0] * params.N[1]
     cells_total = N_global[0] * N_global[1]
     sweeps = 2 * args.steps
@@ -362,7 +368,7 @@ def main():
                    "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local,
-                   "hbm_placement": grid.placement, "device": params.device.name, "halo_exchange": halo_mode},
+                   "hbm_placement": placement, "device": params.device.name, "halo_exchange": halo_mode},
         "hbm_GBps_algorithmic_whole_job": round((32 if args.f32 else 64) * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,
         "self_check": self_check,

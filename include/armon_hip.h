@@ -90,6 +90,12 @@ ARMON_API int armon_hip_sync(armon_ctx* ctx);                                  /
 ARMON_API int armon_hip_device_memory_info(armon_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 ARMON_API int armon_hip_device_name(armon_ctx* ctx, char* buf, size_t buf_len);
 ARMON_API void* armon_hip_stream(armon_ctx* ctx);                              /* the hipStream_t in use     */
+/* Tuning knobs of the fused sweeps (measurement tools and tests; no reference counterpart). A context reads the
+ * environment variables of the same names ONCE, when it is created; this call changes them afterwards.
+ * "ARMON_XS_NITER" strips per wave of the X sweep, "ARMON_Y_SEG" rows per run of the Y march (0 = automatic),
+ * "ARMON_SWEEP_ALIGN" 0 = unaligned block/strip origins, "ARMON_Y_COLS1" 1 = fp32 Y march with one column per lane.
+ * None of them changes a result bit. */
+ARMON_API int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value);
 
 /* device array type support: V{T,1}(undef, n) / copyto! (ref src/blocking/blocks.jl:36-44,121-143) */
 ARMON_API int armon_hip_malloc(armon_ctx* ctx, size_t bytes, void** ptr);
@@ -305,6 +311,15 @@ ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
 ARMON_API int armon_hip_tune_placement(armon_ctx*, const armon_sweep_desc* x_desc, const armon_sweep_desc* y_desc,
         void* const* pool, int n_pool, size_t bytes, int tries, int picks[8], double* times_ms);
 
+/* The same choice for a pool that holds NO state yet — call it BEFORE init_test: nothing has to be parked or restored,
+ * so the only transient memory is the caller's own spare vectors (n_pool - 8 of them). Candidates are timed on a uniform
+ * state the call writes itself (every vector of the pool is overwritten); the search stops early once two draws lie
+ * within `tolerance` (e.g. 0.01; 0 = never) of the best seen, after at most `tries`. picks[role] as above (roles 0..3:
+ * where init_test should put rho,u,v,E; 4..7: their ping-pong partners); *tries_done (nullable) = draws timed. */
+ARMON_API int armon_hip_choose_placement(armon_ctx*, const armon_sweep_desc* x_desc, const armon_sweep_desc* y_desc,
+        void* const* pool, int n_pool, size_t bytes, int tries, double tolerance, int picks[8], double* times_ms,
+        int* tries_done);
+
 typedef struct {
     int32_t axis;            /* ARMON_AXIS_X / _Y                                               */
     int32_t scheme;          /* ARMON_SCHEME_*                                                  */
@@ -346,6 +361,9 @@ typedef struct {
 ARMON_API int armon_hip_sweep_f32(armon_ctx*, const armon_sweep_desc_f32*);
 ARMON_API int armon_hip_tune_placement_f32(armon_ctx*, const armon_sweep_desc_f32* x_desc, const armon_sweep_desc_f32* y_desc,
         void* const* pool, int n_pool, size_t bytes, int tries, int picks[8], double* times_ms);
+ARMON_API int armon_hip_choose_placement_f32(armon_ctx*, const armon_sweep_desc_f32* x_desc, const armon_sweep_desc_f32* y_desc,
+        void* const* pool, int n_pool, size_t bytes, int tries, double tolerance, int picks[8], double* times_ms,
+        int* tries_done);
 
 
 /* ---- multi-GPU: tile-decomposed grid, halo exchange and dt reduction on the device ------------------------------ */

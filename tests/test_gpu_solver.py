@@ -339,11 +339,17 @@ def test_tune_placement_keeps_the_state(oracle):
     for f in before:
         assert np.array_equal(before[f], after[f])
     assert len({grid.data[f].ptr for f in before} | {grid.alt[f].ptr for f in before}) == 8
-    # and a whole run with tuning forced on every block size gives the same result as one without
+    # and whole runs with the placement chosen before init_test (armon_hip_choose_placement, what armon() does at
+    # full size), forced here on a small block, or with no tuning at all, give the oracle's result
     ref, ref_fields = oracle.solve(test="Sod_circ", N=(96, 64), maxcycle=6)
-    _p, stats, host = run("Sod_circ", N=(96, 64), maxcycle=6, placement_tries=1)
-    assert stats.cycles == ref.cycles
-    assert np.array_equal(oracle.real_view(host["rho"], 96, 64, G), oracle.real_view(ref_fields["rho"], 96, 64, G))
+    for opts in (dict(placement_tries=6, placement_min_bytes=0), dict(placement_tries=1)):
+        _p, stats, host = run("Sod_circ", N=(96, 64), maxcycle=6, **opts)
+        assert stats.cycles == ref.cycles
+        assert (stats.data.placement is not None) == (opts["placement_tries"] > 1)
+        if stats.data.placement:
+            rep = stats.data.placement
+            assert 2 <= rep["tries"] <= 6 and len(rep["x_plus_y_ms"]) == rep["tries"] and rep["pool"] == 12
+        assert np.array_equal(oracle.real_view(host["rho"], 96, 64, G), oracle.real_view(ref_fields["rho"], 96, 64, G))
 
 
 @pytest.mark.parametrize("knobs", [dict(ARMON_SWEEP_ALIGN="0"), dict(ARMON_XS_NITER="1"), dict(ARMON_XS_NITER="3"),

@@ -26,7 +26,7 @@ ap.add_argument("--scheme", default="GAD")
 ap.add_argument("--projection", default="euler_2nd")
 ap.add_argument("--f32", action="store_true")
 ap.add_argument("--track-x", action="store_true", help="fused dt/CFL reduction on the X sweep too (X-last splittings)")
-ap.add_argument("--env", default="", help="per-build env: name:KEY=VAL,KEY=VAL;name2:... applied around that build's launches")
+ap.add_argument("--env", default="", help="per-build tuning knobs: name:KEY=VAL,KEY=VAL;name2:... (armon_hip_set_tuning on that build's context)")
 ap.add_argument("--gap-ms", type=float, default=0., help="idle time before every launch (clock/power recovery experiments)")
 ap.add_argument("--copy", action="store_true", help="also time armon_hip_stream_copy4 on the same arrays (same bytes, no arithmetic)")
 ap.add_argument("libs", nargs="+", help="name=path")
@@ -61,9 +61,8 @@ for r in range(args.rounds + 2):
     for axis in (Axis.X, Axis.Y):
         d = sweep_desc(params, grid, axis, dt, dx, emit_dt=axis == Axis.Y or args.track_x)
         for name, L, ctx in builds:
-            for k in knobs:
-                os.environ.pop(k, None)
-            os.environ.update(envs.get(name, {}))
+            for k in knobs:                       # knobs live in the context: reset, then apply this build's values
+                _lib.check(L.armon_hip_set_tuning(ctx, k.encode(), int(envs.get(name, {}).get(k, -1 if k == "ARMON_SWEEP_ALIGN" else 0))))
             if args.gap_ms:
                 time.sleep(args.gap_ms * 1e-3)
             _lib.check(L.armon_hip_event_record(ctx, 0))

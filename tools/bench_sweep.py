@@ -11,6 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import armon_amd
 from armon_amd.blocking import Axis
+from armon_amd._lib import check
 from armon_amd.solver import BlockGrid, fused_sweep, init_test
 
 ap = argparse.ArgumentParser()
@@ -48,10 +49,7 @@ for r in range(args.rounds + 1):
         for axis, xk, nit, sg, al in cfgs:
             params.x_kernel = xk
             for key, val in (("ARMON_XS_NITER", nit), ("ARMON_Y_SEG", sg), ("ARMON_SWEEP_ALIGN", al)):
-                if val:
-                    os.environ[key] = val
-                else:
-                    os.environ.pop(key, None)
+                check(armon_amd.lib().armon_hip_set_tuning(dev.ctx, key.encode(), int(val) if val else (-1 if key == "ARMON_SWEEP_ALIGN" else 0)))
             dev.event_record(0)
             fused_sweep(params, grid, axis, dt, dx, emit_p=args.emit, emit_c=args.emit, emit_dt=args.track and axis == Axis.Y)
             dev.event_record(1)
