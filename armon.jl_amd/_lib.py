@@ -116,6 +116,7 @@ SIGNATURES = {
     "armon_hip_sweep": (_ci, [_vp, C.POINTER(SweepDesc)]),
     "armon_hip_tune_placement": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc), C.POINTER(_vp), _ci,
                                        C.c_size_t, _ci, C.POINTER(_ci * 8), C.POINTER(_dbl)]),
+    "armon_hip_cycle_xy": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc)]),
     "armon_hip_choose_placement": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc), C.POINTER(_vp), _ci,
                                          C.c_size_t, _ci, _dbl, C.POINTER(_ci * 8), C.POINTER(_dbl), C.POINTER(_ci)]),
     "armon_hip_mgpu_init": (_ci, [_ci, _ci, C.POINTER(_ci), C.POINTER(_vp)]),

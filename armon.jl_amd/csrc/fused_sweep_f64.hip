@@ -4,4 +4,5 @@
 #define ARMON_SWEEP_DESC armon_sweep_desc
 #define ARMON_TUNE_FN armon_hip_tune_placement
 #define ARMON_CHOOSE_FN armon_hip_choose_placement
+#define ARMON_CYCLE_FN armon_hip_cycle_xy
 #include "fused_sweep_impl.hpp"

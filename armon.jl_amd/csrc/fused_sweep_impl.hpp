@@ -76,12 +76,16 @@ struct sweep_args {
     int64_t o_lo, o_hi;            // cells to produce along the sweep axis: [o_lo, o_hi)
     int64_t x_first;               // X sweep: first cell of strip 0 (<= o_lo, sector-aligned in the ghosted row)
     int32_t xshift;                // Y sweep: columns the block origin is moved left (line-aligned row segments)
+    int32_t xcd_remap;             // X sweep: XCD-aware workgroup placement (ARMON_X_XCD)
     real dt, dx, gamma;
     real fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const real *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
     real *rho_out, *ua_out, *ut_out, *E_out;
     real *p_out, *c_out;
     real* partials;              // dt/CFL tracking: [2 * n_blocks] (max |u|±c, max |v|±c per workgroup)
+    // whole-cycle kernel only: boundary of the SECOND (y) sweep — mirror flags and (u, v) factors per side
+    int32_t bc_low_t = 0, bc_high_t = 0;
+    real tu_low = 1, tv_low = 1, tu_high = 1, tv_high = 1;
 };
 
 // Source index and velocity factors of cell `j` (0-based real coordinate along the sweep axis, may be
@@ -178,6 +182,27 @@ __device__ __forceinline__ void cfl_block_store(const cfl_track& t, real* partia
     }
 }
 
+constexpr int kFoldBlocks = 512;
+
+// first level of the fold when a launch leaves more partial pairs than one workgroup should walk
+__global__ void __launch_bounds__(256)
+k_fold_pairs(const real* __restrict__ partials, int64_t n, real* __restrict__ out)
+{
+    __shared__ real lds[4];
+    real au = 0, av = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const vec2 v = ld2(partials + 2 * k);
+        au = phys::mx(au, v.x);
+        av = phys::mx(av, v.y);
+    }
+    au = red::block_reduce<red::op_max, 4>(au, lds, threadIdx.x);
+    av = red::block_reduce<red::op_max, 4>(av, lds, threadIdx.x);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = au;
+        out[2 * blockIdx.x + 1] = av;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_fold_dt(const real* __restrict__ partials, int64_t n_blocks, real dx, real dy, real* __restrict__ out,
           int accumulate)
@@ -194,6 +219,21 @@ k_fold_dt(const real* __restrict__ partials, int64_t n_blocks, real dx, real dy,
         const real dt = phys::mn(dx / au, dy / av);
         out[0] = accumulate ? phys::mn(out[0], dt) : dt;
     }
+}
+
+// min(dx / max au, dy / max av) over `n` partial pairs into *out, on the context's stream
+int fold_dt_launch(armon_ctx* ctx, real* partials, int64_t n, real dx, real dy, real* out, int accumulate)
+{
+    if (n > 16384) {
+        real* level1 = partials + 2 * n;                      // room reserved by max_blocks()
+        hipLaunchKernelGGL(k_fold_pairs, dim3(kFoldBlocks), dim3(256), 0, ctx->stream, partials, n, level1);
+        int rc = check_launch("fold_pairs");
+        if (rc != ARMON_OK) return rc;
+        partials = level1;
+        n = kFoldBlocks;
+    }
+    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, partials, n, dx, dy, out, accumulate);
+    return check_launch("fold_dt");
 }
 
 // ---- Y sweep ---------------------------------------------------------------------------------------
@@ -474,17 +514,6 @@ k_sweep_y2(sweep_args a)
 constexpr int kXSRows = ARMON_XS_ROWS;
 constexpr int kXSNiter = 2;      // strips per wave (A/B over 1..137 with tools/ab_sweep.py: short-lived waves keep the global access order sequential)
 
-constexpr int kXSlots = 4096;    // dt/CFL tracking of the X sweep: slots the waves fold their maxima into
-
-__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v)
-{
-    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
-}
-__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v)
-{
-    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
-}
-
 template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
 __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 {
@@ -499,7 +528,20 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     constexpr int STRIDE = WIDTH - 2 * HALO;
 
     const int lane = threadIdx.x;
-    const int64_t row_r = (int64_t)blockIdx.y * kXSRows + threadIdx.y;
+    // XCD-aware placement of the workgroups: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own
+    // L2), so with the plain mapping two strips that are neighbours along x — they share their 4-cell halos — always
+    // sit on different XCDs and both fetch the shared sectors from HBM. Within every group of 8 rows of workgroups,
+    // XCD k (ids ≡ k mod 8) gets the whole row k: neighbouring strips then follow each other on the same L2.
+    unsigned vbx = blockIdx.x, vby = blockIdx.y;
+    if (a.xcd_remap) {
+        const unsigned G = gridDim.x, chunk = vby & ~7u;
+        if (chunk + 8 <= gridDim.y) {                          // whole groups only: the last rows keep the plain mapping
+            const unsigned local = (vby - chunk) * G + vbx;    // 0 .. 8G-1 in dispatch order
+            vby = chunk + (local & 7u);
+            vbx = local >> 3;
+        }
+    }
+    const int64_t row_r = (int64_t)vby * kXSRows + threadIdx.y;
     const bool row_ok = row_r < a.ny;                         // whole wave
     const int64_t row = row_ok ? row_r : a.ny - 1;
     const int64_t row_off = (row + a.g) * a.row_len + a.g;
@@ -514,7 +556,7 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 
     // Strip origins are aligned so that a strip's stores start on a 64-B sector of the ghosted row (for the
     // usual STRIDE = 120 = 15 sectors); the first strip of a row is then a short one (stores masked below o_lo).
-    const int64_t w_first = a.x_first + (int64_t)blockIdx.x * niter * STRIDE;
+    const int64_t w_first = a.x_first + (int64_t)vbx * niter * STRIDE;
     // Strips are real-buffered in registers: the loads of strip it+1 are issued before strip it is
     // computed (the loop is unrolled by the two buffers, so no loaded register is ever copied).
     St buf[2][4];
@@ -609,26 +651,125 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
             do_strip(std::integral_constant<int, 1>{}, it + 1);
         }
     }
-    // The waves of this kernel are short-lived (2 strips): a block-level LDS reduction + one partial per block
-    // cost more than the strips themselves (282k blocks at 16384²: +1.1 ms). Each wave folds its two maxima
-    // into one of kXSlots slots with an integer atomic max instead (bit patterns of non-negative IEEE numbers
-    // are ordered like the numbers; max is order-independent, so the result stays deterministic).
+    // The waves of this kernel are short-lived (2 strips): a block-level LDS reduction + one partial per block cost
+    // more than the strips themselves (282k blocks at 16384²: +1.1 ms), and atomic maxima into shared slots go to the
+    // memory side on this part (2.3 M of them: +0.5 ms). Each wave simply stores its two maxima in its own slot
+    // (18 MB at 16384², 0.1 % of the sweep's traffic); fold_dt_launch reduces them in two levels.
     if (TRACK) {
         const real au = red::wave_reduce<red::op_max>(cfl.au), av = red::wave_reduce<red::op_max>(cfl.av);
         if (lane == 0) {
             const int64_t wave_id = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kXSRows + threadIdx.y;
-            real* slot = a.partials + 2 * (wave_id & (kXSlots - 1));
-            atomic_max_nonneg(slot, au);
-            atomic_max_nonneg(slot + 1, av);
+            st2(a.partials + 2 * wave_id, au, av);
         }
     }
 }
 
+#ifndef ARMON_XS_WAVES
+#define ARMON_XS_WAVES 1         // minimum waves per SIMD the X sweep is compiled for (tuning macro; 3 = cap at 168 VGPRs)
+#endif
 template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
-__global__ void __launch_bounds__(64 * kXSRows)
+__global__ void __launch_bounds__(64 * kXSRows, ARMON_XS_WAVES)
 k_sweep_x_dpp(sweep_args a, int niter)
 {
     sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK>(a, niter);
+}
+
+// ---- whole cycle X then Y in ONE pass over memory (Sequential splitting) -----------------------------------------
+// A wave owns 64 consecutive columns (56 produced + the X sweep's 4-cell halo on both sides) and marches down y:
+// each step loads one row segment, sweeps it along x in place (lanes along x, DPP shifts: SpatialSweep<K = 1>) and
+// feeds the X-swept cell of every lane straight into that lane's Y pipeline (the register march of k_sweep_y): the
+// intermediate state between the two sweeps of the reference's cycle (ref src/solver.jl:300-316 executed for X,
+// then for Y) never leaves the registers. 32 B read + 32 B written per cell per CYCLE instead of per sweep.
+#ifndef ARMON_C_PF
+#define ARMON_C_PF 3
+#endif
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, bool TRACK>
+#ifndef ARMON_C_WAVES
+#define ARMON_C_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, ARMON_C_WAVES)
+k_cycle_xy(sweep_args a, real dt_y, real dx_y)
+{
+    using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, 1, real>;
+    using PIPE = typename std::conditional<EXACT, fused::Pipe<SCHEME, LIM, PROJ, EOS, real>, fused::PipeFast<SCHEME, LIM, PROJ, EOS, real>>::type;
+    using St = fused::Strip<1, real>;
+    constexpr int LAG = PIPE::LAG, PF = ARMON_C_PF, VALID = 64 - 2 * LAG;
+    const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
+    const int lane = threadIdx.x & 63, wave = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int xr = wave * VALID - LAG + lane;                 // this lane's column (may be a ghost: -LAG .. nx + LAG - 1)
+    const bool produces = lane >= LAG && lane < 64 - LAG && xr < nx;
+    // X boundary: mirror of the inside (ref src/halo_exchange.jl:2-29) or ghost columns filled by the halo exchange
+    int xs = xr < -g ? -g : (xr > nx + g - 1 ? nx + g - 1 : xr);
+    real fxa = 1, fxt = 1;
+    if (xs < 0 && a.bc_low) { fxa = a.fa_low; fxt = a.ft_low; xs = -1 - xs; }
+    else if (xs >= nx && a.bc_high) { fxa = a.fa_high; fxt = a.ft_high; xs = 2 * nx - 1 - xs; }
+    const int o_hi = (int)a.o_hi;
+    const int o0 = (int)a.o_lo + (int)blockIdx.y * a.seg;
+    const int o1 = (o0 + a.seg < o_hi) ? o0 + a.seg : o_hi;
+    const int jb = o0 - LAG, je = o1 + LAG;
+
+    const unsigned colb = (unsigned)(xs + g) * (unsigned)sizeof(real), colw = (unsigned)(xr + g) * (unsigned)sizeof(real);
+    const unsigned pitchb = (unsigned)a.row_len * (unsigned)sizeof(real);
+    const int64_t in_base = (int64_t)(jb + g) * a.row_len, out_base = (int64_t)(o0 + g) * a.row_len;
+    // X sweep: ua = u, ut = v
+    const rsrc_t r_rho = make_rsrc(a.rho_in + in_base), r_u = make_rsrc(a.ua_in + in_base);
+    const rsrc_t r_v = make_rsrc(a.ut_in + in_base), r_E = make_rsrc(a.E_in + in_base);
+    const rsrc_t w_rho = make_rsrc(a.rho_out + out_base), w_u = make_rsrc(a.ua_out + out_base);
+    const rsrc_t w_v = make_rsrc(a.ut_out + out_base), w_E = make_rsrc(a.E_out + out_base);
+
+    SW sw{a.dt, a.dx, a.gamma};
+    PIPE pipe(dt_y, dx_y, a.gamma);
+    cfl_track cfl;
+    // Y boundary factors act on the X-swept state exactly as the reference's mirror does between its two sweeps
+    St raw[PF + 1][4];
+    int lj = jb;
+    unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;
+    auto load = [&](auto slot) {
+        constexpr int K = decltype(slot)::value % (PF + 1);
+        const bool m_lo = lj < 0 && a.bc_low_t, m_hi = lj >= ny && a.bc_high_t;
+        const int src = m_lo ? -1 - lj : (m_hi ? 2 * ny - 1 - lj : lj);
+        const unsigned off = (unsigned)(src - jb) * pitchb;
+        // transverse (y) mirror: v flips with the Y factor, u with its own
+        const real fu = (m_lo ? a.tu_low : (m_hi ? a.tu_high : real(1))) * fxa;
+        const real fv = (m_lo ? a.tv_low : (m_hi ? a.tv_high : real(1))) * fxt;
+        raw[K][0].v[0] = buf_load<real>(r_rho, colb, off);
+        raw[K][1].v[0] = buf_load<real>(r_u, colb, off) * fu;
+        raw[K][2].v[0] = buf_load<real>(r_v, colb, off) * fv;
+        raw[K][3].v[0] = buf_load<real>(r_E, colb, off);
+        if (lj + 1 < je) lj++;
+    };
+    auto step = [&](auto ph, int j) {
+        constexpr int PH = decltype(ph)::value;              // multiple-of-(8·(PF+1)) unroll: both rings by phase
+        constexpr int PH8 = PH & 7, KR = PH % (PF + 1);
+        St o_rho, o_u, o_v, o_E, p, cs;
+        sw.run(raw[KR][0], raw[KR][1], raw[KR][2], raw[KR][3], o_rho, o_u, o_v, o_E, p, cs);
+        load(std::integral_constant<int, PH + PF + 1>{});     // row j + PF + 1 → the slot just consumed
+        real pj, cj, c_lag;
+        const fused::Out4<real> out = pipe.template push<true, PH8>(o_rho.v[0], o_v.v[0], o_u.v[0], o_E.v[0], pj, cj, c_lag);
+        const int o = j - LAG;
+        if (a.emit && j >= o0 && j < o1 && produces) {
+            const unsigned off = so_off + LAG * pitchb;
+            if (a.emit & 1) buf_store(make_rsrc(a.p_out + out_base), colw, off, pj);
+        }
+        if (o >= o0 && o < o1) {
+            if (produces) {
+                buf_store(w_rho, colw, so_off, out.rho);
+                buf_store(w_u, colw, so_off, out.ut);         // Y pipeline: ut = u, ua = v
+                buf_store(w_v, colw, so_off, out.ua);
+                buf_store(w_E, colw, so_off, out.E);
+                if (TRACK) cfl.add(out.ut, out.ua, c_lag);
+            }
+        }
+        so_off += pitchb;
+    };
+    constexpr int U = 8 * (PF + 1);
+    static_for(std::make_integer_sequence<int, PF + 1>{}, [&](auto k) { load(k); });
+    const int T = je - jb;
+    for (int t = 0; t < T; t += U)
+        static_for(std::make_integer_sequence<int, U>{}, [&](auto ph) {
+            if (t + decltype(ph)::value < T) step(ph, jb + t + decltype(ph)::value);
+        });
+    if (TRACK) cfl_block_store<4>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
 
 // ---- X sweep, LDS-transposed march (alternative form) -----------------------------------------------------
@@ -764,12 +905,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     const int halo = k1 ? PIPE::LAG : 4;
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
     dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
-    *n_blocks = (int64_t)grid.x * grid.y;
-    if (TRACK) {
-        if (hipMemsetAsync(a.partials, 0, 2 * kXSlots * sizeof(real), ctx->stream) != hipSuccess)
-            return check_launch("sweep_x_dpp (slots)");
-        *n_blocks = kXSlots;
-    }
+    *n_blocks = (int64_t)grid.x * grid.y * kXSRows;          // one pair of maxima per wave
 #ifndef ARMON_ONLY_HEADLINE
     if (k1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
@@ -815,10 +951,10 @@ int64_t max_blocks(const sweep_args& a)
 {
     const int64_t by = (a.nx + 16 + kYBlock - 1) / kYBlock * ((a.ny + a.seg - 1) / a.seg);
     const int64_t bx_lds = (a.nx + a.seg - 1) / a.seg * ((a.ny + kXRows - 1) / kXRows);
-    const int64_t bx_dpp = ((a.nx + 8) / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows);     // niter >= 1, K = 1, LAG = 4
+    const int64_t bx_dpp = ((a.nx + 8) / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows) * kXSRows;     // per wave; niter >= 1, K = 1, LAG = 4
     int64_t m = by > bx_lds ? by : bx_lds;
     m = m > bx_dpp ? m : bx_dpp;
-    return m > kXSlots ? m : kXSlots;
+    return m + kFoldBlocks;                                   // + the first-level results of fold_dt_launch
 }
 
 template <class PIPE>
@@ -933,6 +1069,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     const bool align = ctx->tune_align != 0;
     a.xshift = (X || !align) ? 0 : d->nghost % 16;
     a.x_first = X ? (align ? a.o_lo - (a.o_lo + d->nghost) % 8 : a.o_lo) : 0;
+    a.xcd_remap = ctx->tune_x_xcd;
     a.partials = nullptr;
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));
@@ -944,12 +1081,10 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     int rc;
 #ifdef ARMON_ONLY_HEADLINE   // variant builds for A/B timing (tools/build_variant.sh): one instantiation, seconds to compile
     ARMON_REQUIRE(d->scheme == ARMON_SCHEME_GAD && d->limiter == ARMON_LIMITER_MINMOD && d->projection == ARMON_PROJECTION_EULER_2ND &&
-                  d->eos == ARMON_EOS_PERFECT_GAS && !exact && d->x_kernel == 0, "headline-only variant build");
-    rc = dispatch_track<fused::PipeFast<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD, ARMON_PROJECTION_EULER_2ND, ARMON_EOS_PERFECT_GAS, real>>(
-        ctx, a, d->axis, track, &n_blocks);
+                  d->eos == ARMON_EOS_PERFECT_GAS && d->x_kernel == 0, "headline-only variant build");
+    rc = dispatch_exact<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD, ARMON_PROJECTION_EULER_2ND, ARMON_EOS_PERFECT_GAS>(ctx, a, d->axis, exact, track, &n_blocks);
     if (rc != ARMON_OK || !track) return rc;
-    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
-    return check_launch("fold_dt");
+    return fold_dt_launch(ctx, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
 #else
     if (d->scheme == ARMON_SCHEME_GODUNOV) {
         rc = dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact, track, &n_blocks);
@@ -966,8 +1101,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
         }
     }
     if (rc != ARMON_OK || !track) return rc;
-    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
-    return check_launch("fold_dt");
+    return fold_dt_launch(ctx, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
 #endif
 }
 
@@ -1055,8 +1189,9 @@ extern "C" int ARMON_TUNE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, con
 // Same choice for a pool that holds NO state worth keeping (a host calls it BEFORE init_test writes the initial
 // condition): nothing is parked or restored, so the only transient memory is the caller's spare vectors. Each
 // candidate's four input vectors are filled with a uniform state (the sweeps' instruction stream does not depend on the
-// data) and timed like above; the search stops as soon as two draws lie within `tolerance` of the best one seen (the
-// good placements form a plateau), after at most `tries` draws.
+// data) and timed like above; the search stops as soon as two draws lie within `tolerance` of the best one seen while
+// a draw at least 3 % slower has been seen as well (the good placements form a plateau), after at most
+// `tries` draws.
 namespace {
 __global__ void __launch_bounds__(256) k_fill_uniform(real* __restrict__ p, size_t n, real value)
 {
@@ -1121,9 +1256,15 @@ extern "C" int ARMON_CHOOSE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, c
             best_ms = ms_min;
             for (int k = 0; k < 8; k++) best[k] = idx[k];
         }
+        // stop once the plateau of good placements has been hit twice — two draws within `tolerance` of the best —
+        // AND a clearly slower draw has been seen too (two equal draws alone may both be bad ones)
         int near = 0;
-        for (double v : seen) near += v <= best_ms * (1. + tolerance);
-        if (tolerance > 0 && near >= 2 && t >= 1) { t++; break; }
+        double worst = 0;
+        for (double v : seen) {
+            near += v <= best_ms * (1. + tolerance);
+            worst = v > worst ? v : worst;
+        }
+        if (tolerance > 0 && near >= 2 && best_ms <= 0.97 * worst) { t++; break; }
     }
 #undef CHOOSE_TRY
     for (int k = 0; k < 8; k++) picks[k] = best[k];
@@ -1131,3 +1272,97 @@ extern "C" int ARMON_CHOOSE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, c
     cleanup();
     return ARMON_OK;
 }
+
+// ---- whole cycle (X sweep then Y sweep, Sequential splitting) in one launch: k_cycle_xy --------------------------------
+#ifdef ARMON_CYCLE_FN
+extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const ARMON_SWEEP_DESC* y)
+{
+    ARMON_REQUIRE(ctx && x && y, "NULL argument");
+    ARMON_REQUIRE(x->axis == ARMON_AXIS_X && y->axis == ARMON_AXIS_Y, "expected an X descriptor then a Y descriptor");
+    ARMON_REQUIRE(x->scheme == y->scheme && x->limiter == y->limiter && x->projection == y->projection && x->eos == y->eos &&
+                  x->exact == y->exact && x->nghost == y->nghost && x->nx == y->nx && x->ny == y->ny && x->gamma == y->gamma,
+                  "the two sweeps of a cycle must share scheme, limiter, projection, EOS, arithmetic and block shape");
+    ARMON_REQUIRE(x->scheme == ARMON_SCHEME_GAD && x->limiter == ARMON_LIMITER_MINMOD && x->projection == ARMON_PROJECTION_EULER_2ND &&
+                  x->eos == ARMON_EOS_PERFECT_GAS && !x->exact, "whole-cycle kernel: GAD + minmod + euler_2nd, perfect gas, tuned arithmetic only");
+    ARMON_REQUIRE(x->nx > 0 && x->ny > 0 && x->nx < (1ll << 30) && x->ny < (1ll << 30), "invalid block %lld x %lld", (long long)x->nx, (long long)x->ny);
+    ARMON_REQUIRE(x->out_hi == 0 && !x->p_out && !x->c_out && !x->dt_cfl_out, "partial X sweeps / X outputs are not available in the whole-cycle kernel");
+    ARMON_REQUIRE(x->rho_in && x->u_in && x->v_in && x->E_in && y->rho_out && y->u_out && y->v_out && y->E_out, "NULL state array");
+    ARMON_REQUIRE(x->rho_in != y->rho_out && x->u_in != y->u_out && x->v_in != y->v_out && x->E_in != y->E_out, "in and out arrays must not alias");
+    constexpr int lag = 4;
+    ARMON_REQUIRE(x->nghost >= lag && x->nx >= lag && x->ny >= lag, "needs at least %d ghost layers and cells per axis", lag);
+    const bool track = y->dt_cfl_out != nullptr;
+    ARMON_REQUIRE(!track || (y->cfl_dx > 0 && y->cfl_dy > 0), "dt_cfl_out needs cfl_dx, cfl_dy > 0");
+
+    sweep_args a;
+    a.nx = x->nx;
+    a.ny = x->ny;
+    a.row_len = x->nx + 2 * (int64_t)x->nghost;
+    a.g = x->nghost;
+    a.bc_low = x->bc_low;
+    a.bc_high = x->bc_high;
+    a.emit = y->p_out ? 1 : 0;
+    a.dt = (real)x->dt;
+    a.dx = (real)x->dx;
+    a.gamma = (real)x->gamma;
+    a.fa_low = (real)x->u_factor_low;     // X sweep: axial = u, transverse = v
+    a.ft_low = (real)x->v_factor_low;
+    a.fa_high = (real)x->u_factor_high;
+    a.ft_high = (real)x->v_factor_high;
+    a.bc_low_t = y->bc_low;
+    a.bc_high_t = y->bc_high;
+    a.tu_low = (real)y->u_factor_low;
+    a.tv_low = (real)y->v_factor_low;
+    a.tu_high = (real)y->u_factor_high;
+    a.tv_high = (real)y->v_factor_high;
+    a.rho_in = x->rho_in; a.ua_in = x->u_in; a.ut_in = x->v_in; a.E_in = x->E_in;
+    a.rho_out = y->rho_out; a.ua_out = y->u_out; a.ut_out = y->v_out; a.E_out = y->E_out;
+    a.p_out = y->p_out;
+    a.c_out = nullptr;
+    a.x_kernel = 0;
+    a.x_first = 0;
+    a.xshift = 0;
+    a.xcd_remap = 0;
+    a.o_lo = 0;
+    a.o_hi = x->ny;
+    if (y->out_hi != 0) {
+        ARMON_REQUIRE(y->out_lo >= 0 && y->out_lo < y->out_hi && y->out_hi <= x->ny, "invalid partial sweep");
+        a.o_lo = y->out_lo;
+        a.o_hi = y->out_hi;
+    }
+    const int64_t waves_x = (x->nx + 55) / 56, blocks_x = (waves_x + 3) / 4;
+    {   // run length: same model as the Y march, with this kernel's residency (ARMON_C_WAVES waves per SIMD)
+        const double slots = (double)ctx->n_cu * ARMON_C_WAVES;
+        int best = (int)(x->ny < 32 ? x->ny : 32);
+        double best_cost = 1e300;
+        for (int64_t nruns = 1; nruns <= x->ny; nruns++) {
+            const int64_t seg = (x->ny + nruns - 1) / nruns;
+            if (seg < 32) break;
+            if ((x->ny + seg - 1) / seg != nruns) continue;
+            const double rounds = (double)(blocks_x * nruns) / slots;
+            if (rounds < 2.) continue;
+            const double cost = 0.5 * (rounds + std::ceil(rounds)) * (double)(seg + 2 * lag);
+            if (cost < best_cost) { best_cost = cost; best = (int)seg; }
+        }
+        a.seg = ctx->tune_y_seg > 0 ? ctx->tune_y_seg : best;
+    }
+    ARMON_REQUIRE(a.row_len * (int64_t)sizeof(real) * (a.seg + 2 * lag + 16) < (1ll << 32), "block too wide for 32-bit row offsets");
+    const int64_t n_out = a.o_hi - a.o_lo;
+    dim3 grid((unsigned)blocks_x, (unsigned)((n_out + a.seg - 1) / a.seg));
+    const int64_t n_blocks = (int64_t)grid.x * grid.y;
+    a.partials = nullptr;
+    if (track) {
+        int rc = ensure_partials(ctx, (size_t)(2 * n_blocks));
+        if (rc != ARMON_OK) return rc;
+        a.partials = reinterpret_cast<real*>(ctx->partials);
+    }
+    constexpr int S = ARMON_SCHEME_GAD, L = ARMON_LIMITER_MINMOD, P = ARMON_PROJECTION_EULER_2ND, E = ARMON_EOS_PERFECT_GAS;
+    if (track)
+        hipLaunchKernelGGL((k_cycle_xy<S, L, P, E, false, true>), grid, dim3(256), 0, ctx->stream, a, (real)y->dt, (real)y->dx);
+    else
+        hipLaunchKernelGGL((k_cycle_xy<S, L, P, E, false, false>), grid, dim3(256), 0, ctx->stream, a, (real)y->dt, (real)y->dx);
+    int rc = check_launch("cycle_xy");
+    if (rc != ARMON_OK || !track) return rc;
+    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, a.partials, n_blocks, (real)y->cfl_dx, (real)y->cfl_dy, y->dt_cfl_out, y->dt_accumulate);
+    return check_launch("fold_dt");
+}
+#endif

@@ -42,6 +42,117 @@ struct PipeTraits {
 };
 
 // ======================================================================================================
+// Correctly rounded division and square root at speed (exact flavour)
+// ======================================================================================================
+// The compiler's IEEE a/b is v_div_scale ×2, v_rcp_f64, two Newton steps, quotient, remainder, v_div_fmas,
+// v_div_fixup: 11 instructions, 20 times per cell. The scale / fix-up instructions only act when an operand or
+// the quotient leaves ~2^±500 (or is 0, inf, NaN); everything the solver divides is within 1e±30, and there the
+// remaining operations — reproduced below in the same order — give the same, correctly rounded bits (asserted by
+// every bit-parity test against the oracle, which divides with the CPU's IEEE instruction). A prepared denominator
+// (reciprocal refined once: 5 instructions) then serves every quotient that shares it for 3 instructions each:
+// the two Godunov quotients (ref src/riemann_schemes.jl:27-28), the three u,v,E of the projection, its four /dx,
+// the two dt/dm of the cell update, consecutive slope ratios.
+namespace xct {
+
+template <typename T> struct Den;
+
+// fp32: the compiler's own expansion (it toggles the denormal mode around its FMAs; nothing to share cheaply)
+template <> struct Den<float> {
+    float b;
+    __device__ __forceinline__ Den() : b(1.f) {}
+    __device__ __forceinline__ explicit Den(float b_) : b(b_) {}
+    __device__ __forceinline__ float quo(float a) const { return a / b; }
+    __device__ __forceinline__ Den twice() const { return Den(2.f * b); }
+};
+
+#ifdef ARMON_XCT_PLAIN   // A/B builds: the compiler's IEEE expansion everywhere (tools/build_variant.sh)
+template <> struct Den<double> {
+    double b;
+    __device__ __forceinline__ Den() : b(1.) {}
+    __device__ __forceinline__ explicit Den(double b_) : b(b_) {}
+    __device__ __forceinline__ double quo(double a) const { return a / b; }
+    __device__ __forceinline__ Den twice() const { return Den(2. * b); }
+};
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+#else
+template <> struct Den<double> {
+    double b, r;                                     // denominator and its reciprocal (≤ 1 ulp)
+    __device__ __forceinline__ Den() : b(1.), r(1.) {}
+    __device__ __forceinline__ explicit Den(double b_) : b(b_)
+    {
+        double y = __builtin_amdgcn_rcp(b_);
+        double e = __builtin_fma(-b_, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-b_, y, 1.0);
+        r = __builtin_fma(y, e, y);
+    }
+    __device__ __forceinline__ double quo(double a) const       // a / b
+    {
+        const double q = a * r;
+        const double rem = __builtin_fma(-b, q, a);
+        return __builtin_fma(rem, r, q);
+    }
+    __device__ __forceinline__ Den twice() const                // the denominator 2·b (exact scaling)
+    {
+        Den d;
+        d.b = 2. * b;
+        d.r = 0.5 * r;
+        return d;
+    }
+};
+
+__device__ __forceinline__ double sqrt_(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x == 0.) ? x : g;
+}
+#endif
+__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+
+// ref src/kernels.jl:4-13
+template <typename T>
+__device__ __forceinline__ void perfect_gas(T gamma, T rho, T E, T u, T v, T& p, T& c)
+{
+    const T e = E - T(0.5) * (u * u + v * v);
+    p = (gamma - T(1.)) * rho * e;
+    c = sqrt_(Den<T>(rho).quo(gamma * p));
+}
+
+// ref src/kernels.jl:16-55 without f3 / pk0second / g (never read by the sweep)
+template <typename T>
+__device__ __forceinline__ void bizarrium(T rho, T E, T u, T v, T& p, T& c)
+{
+    const T rho0 = T(10000.), K0 = T(1e+11), Cv0 = T(1000.), T0 = T(300.), eps0 = T(0.), G0 = T(1.5), s = T(1.5);
+    const T q = T(-42080895. / 14941154.), rr = T(727668333. / 149411540.);
+    const Den<T> d_rho(rho);
+    T x = Den<T>(rho0).quo(rho) - 1;
+    T G = G0 * (1 - d_rho.quo(rho0));
+    T x2 = x * x, x3 = x * x * x;
+    T opx = 1 + x, opx2 = opx * opx, opx3 = opx * opx * opx;
+    const Den<T> d_sx(1 - s * x);
+    T f0 = d_sx.quo(1 + (s / 3 - 2) * x + q * x2 + rr * x3);
+    T f1 = d_sx.quo(s / 3 - 2 + 2 * q * x + 3 * rr * x2 + s * f0);
+    T f2 = d_sx.quo(2 * q + 6 * rr * x + 2 * s * f1);
+    T epsk0 = eps0 - Cv0 * T0 * (1 + G) + T(0.5) * (K0 / rho0) * x2 * f0;
+    T pk0 = -Cv0 * T0 * G0 * rho0 + T(0.5) * K0 * x * opx2 * (2 * f0 + x * f1);
+    T pk0prime = -T(0.5) * K0 * opx3 * rho0 *
+                 (2 * (1 + 3 * x) * f0 + 2 * x * (2 + 3 * x) * f1 + x2 * opx * f2);
+    T e = E - T(0.5) * (u * u + v * v);
+    p = pk0 + G0 * rho0 * (e - epsk0);
+    c = d_rho.quo(sqrt_(G0 * rho0 * (p - pk0) - pk0prime));
+}
+
+}  // namespace xct
+
+// ======================================================================================================
 // EXACT pipeline
 // ======================================================================================================
 template <int SCHEME, int LIM, int PROJ, int EOS, typename T = double>
@@ -51,10 +162,13 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     static constexpr int S = TR::S, W = TR::W, LAG = TR::LAG;
     static constexpr bool kExact = true;
 
+    using Den = xct::Den<T>;
     struct Cell { T rho, ua, ut, E, p, rc; };                 // pre-sweep state + EOS
-    struct Upd { T rho, ua, ut, E, q_ua, q_ut, q_E, dxl; };   // Lagrangian (post cell_update) state
+    struct Upd { T rho, ua, ut, E, q_ua, q_ut, q_E; Den dxl; };   // Lagrangian (post cell_update) state; dxl prepared as a denominator
 
     T dt, dx, gamma;
+    Den d_dx;                   // the uniform denominator dx
+    Den dsum[2];                // (dxl[cu-1] + dxl[cu]) of this / the previous step: r₊ of one cell, r₋ of the next
     Cell c[8];                  // ring of 8: cells j+4 .. j (prefetched), j-1, j-2
     T gus[4], gps[4];      // ring: first-order solutions at interfaces j, j-1, j-2
     T fus[4], fps[4];      // ring: final fluxes at interfaces nf .. nf-3
@@ -63,15 +177,16 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     T a[2][4];             // advection fluxes at interfaces na / na-1
     T csr[4];              // ring: sound speed of cells j .. j-3 (dt/CFL tracking only)
 
-    __device__ __forceinline__ Pipe(T dt_, T dx_, T gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
+    __device__ __forceinline__ Pipe(T dt_, T dx_, T gamma_) : dt(dt_), dx(dx_), gamma(gamma_), d_dx(dx_)
     {
+        dsum[0] = dsum[1] = Den(dx_ + dx_);
         // Neutral, finite start values: the first 2*LAG outputs are discarded by the caller.
 #pragma unroll
         for (int k = 0; k < 8; k++) c[k] = Cell{T(1.), T(0.), T(0.), T(1.), T(1.), T(1.)};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             gus[k] = T(0.); gps[k] = T(1.); fus[k] = T(0.); fps[k] = T(1.); csr[k] = T(1.);
-            l[k] = Upd{T(1.), T(0.), T(0.), T(1.), T(0.), T(0.), T(1.), dx_};
+            l[k] = Upd{T(1.), T(0.), T(0.), T(1.), T(0.), T(0.), T(1.), d_dx};
             s[0][k] = s[1][k] = T(0.);
             a[0][k] = a[1][k] = T(0.);
         }
@@ -104,12 +219,8 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         T p, cs;
         {
             const T u = Y_AXIS ? c0.ut : c0.ua, v = Y_AXIS ? c0.ua : c0.ut;
-            if (EOS == ARMON_EOS_BIZARRIUM) {
-                T g_unused;
-                phys::bizarrium<false>(c0.rho, c0.E, u, v, p, cs, g_unused);
-            } else {
-                phys::perfect_gas(gamma, c0.rho, c0.E, u, v, p, cs);
-            }
+            if (EOS == ARMON_EOS_BIZARRIUM) xct::bizarrium(c0.rho, c0.E, u, v, p, cs);
+            else xct::perfect_gas(gamma, c0.rho, c0.E, u, v, p, cs);
         }
         p_j = p;
         c_j = cs;
@@ -117,25 +228,26 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         c0.p = p;
         c0.rc = c0.rho * cs;
 
-        // ---- first-order acoustic solve at interface j (ref src/riemann_schemes.jl:21-30)
+        // ---- first-order acoustic solve at interface j (ref src/riemann_schemes.jl:21-30): one denominator
         {
             const T rc_l = c1.rc, rc_r = c0.rc;
-            gus[R0] = (rc_l * c1.ua + rc_r * c0.ua + (c1.p - c0.p)) / (rc_l + rc_r);
-            gps[R0] = (rc_r * c1.p + rc_l * c0.p + rc_l * rc_r * (c1.ua - c0.ua)) / (rc_l + rc_r);
+            const Den d(rc_l + rc_r);
+            gus[R0] = d.quo(rc_l * c1.ua + rc_r * c0.ua + (c1.p - c0.p));
+            gps[R0] = d.quo(rc_r * c1.p + rc_l * c0.p + rc_l * rc_r * (c1.ua - c0.ua));
         }
 
         // ---- final flux at interface nf = j - S
         if (S == 1) {
             // acoustic_GAD! at interface i = j-1: cells i-s = c2, i = c1 (ref src/riemann_schemes.jl:84-104)
             const T gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
-            const T r_um = phys::limiter<LIM>((gus0 - c1.ua) / (gus1 - c2.ua + T(1e-6)));
-            const T r_pm = phys::limiter<LIM>((gps0 - c1.p) / (gps1 - c2.p + T(1e-6)));
-            const T r_up = phys::limiter<LIM>((c2.ua - gus2) / (c1.ua - gus1 + T(1e-6)));
-            const T r_pp = phys::limiter<LIM>((c2.p - gps2) / (c1.p - gps1 + T(1e-6)));
+            const T r_um = phys::limiter<LIM>(Den(gus1 - c2.ua + T(1e-6)).quo(gus0 - c1.ua));
+            const T r_pm = phys::limiter<LIM>(Den(gps1 - c2.p + T(1e-6)).quo(gps0 - c1.p));
+            const T r_up = phys::limiter<LIM>(Den(c1.ua - gus1 + T(1e-6)).quo(c2.ua - gus2));
+            const T r_pp = phys::limiter<LIM>(Den(c1.p - gps1 + T(1e-6)).quo(c2.p - gps2));
             const T dm_l = c2.rho * dx;
             const T dm_r = c1.rho * dx;
             const T Dm = (dm_l + dm_r) / 2;
-            const T theta = T(0.5) * (1 - (c2.rc + c1.rc) / 2 * (dt / Dm));
+            const T theta = T(0.5) * (1 - (c2.rc + c1.rc) / 2 * Den(Dm).quo(dt));
             fus[R0] = gus1 + theta * (r_up * (c1.ua - gus1) - r_um * (gus1 - c2.ua));
             fps[R0] = gps1 + theta * (r_pp * (c1.p - gps1) - r_pm * (gps1 - c2.p));
         } else {
@@ -149,12 +261,12 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
             const Cell& cc = (S == 1) ? c2 : c1;
             Upd& n = l[R0];
             const T dm = cc.rho * dx;
-            const T dxl = dx + dt * (fus0 - fus1);
-            n.dxl = dxl;
-            n.rho = dm / dxl;
-            n.ua = cc.ua + dt / dm * (fps1 - fps0);
+            n.dxl = Den(dx + dt * (fus0 - fus1));
+            n.rho = n.dxl.quo(dm);
+            const T dt_dm = Den(dm).quo(dt);
+            n.ua = cc.ua + dt_dm * (fps1 - fps0);
             n.ut = cc.ut;
-            n.E = cc.E + dt / dm * (fps1 * fus1 - fps0 * fus0);
+            n.E = cc.E + dt_dm * (fps1 * fus1 - fps0 * fus0);
             n.q_ua = n.rho * n.ua;
             n.q_ut = n.rho * n.ut;
             n.q_E = n.rho * n.E;
@@ -167,8 +279,11 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         if (W == 1) {
             // slopes of cell cu-1 (ref src/projection_schemes.jl:105-116 evaluated per donor cell);
             // s[P1] still holds the slopes of cell cu-2 from the previous step.
-            const T r_m = (2 * l1.dxl) / (l1.dxl + l2.dxl);
-            const T r_p = (2 * l1.dxl) / (l1.dxl + l0.dxl);
+            // r₋ = 2Δx/(Δx + Δx₋), r₊ = 2Δx/(Δx + Δx₊): this cell's Δx + Δx₊ is the next cell's Δx₋ + Δx (same bits:
+            // IEEE addition commutes), so each sum is prepared once, by the step that first needs it
+            dsum[P0] = Den(l1.dxl.b + l0.dxl.b);
+            const T r_m = dsum[P1].quo(2 * l1.dxl.b);
+            const T r_p = dsum[P0].quo(2 * l1.dxl.b);
             // reference order of the conserved quantities: ρ, ρu, ρv, ρE
             s[P0][0] = phys::slope_minmod(l2.rho, l1.rho, l0.rho, r_m, r_p);
             s[P0][Y_AXIS ? 2 : 1] = phys::slope_minmod(l2.q_ua, l1.q_ua, l0.q_ua, r_m, r_p);
@@ -179,7 +294,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
             const bool up = disp > 0;
             const Upd& d = up ? l2 : l1;
             const T Dxe = up ? -(dx - dt * fus3) : (dx + dt * fus1);
-            const T lf = Dxe / (2 * d.dxl);
+            const T lf = d.dxl.twice().quo(Dxe);
             const T q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
             a[P0][0] = disp * (d.rho - (up ? s[P1][0] : s[P0][0]) * lf);
             a[P0][1] = disp * (q1 - (up ? s[P1][1] : s[P0][1]) * lf);
@@ -204,18 +319,19 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     __device__ __forceinline__ Out4<T> project(const Upd& lo) const
     {
         constexpr int P1 = P0 ^ 1;
-        const T dX = lo.dxl;
+        const T dX = lo.dxl.b;
         const T u = Y_AXIS ? lo.ut : lo.ua, v = Y_AXIS ? lo.ua : lo.ut;   // reference's (u, v)
-        const T t_rho  = (dX * lo.rho        - (a[P0][0] - a[P1][0])) / dx;
-        const T t_urho = (dX * lo.rho * u    - (a[P0][1] - a[P1][1])) / dx;
-        const T t_vrho = (dX * lo.rho * v    - (a[P0][2] - a[P1][2])) / dx;
-        const T t_Erho = (dX * lo.rho * lo.E - (a[P0][3] - a[P1][3])) / dx;
+        const T t_rho  = d_dx.quo(dX * lo.rho        - (a[P0][0] - a[P1][0]));
+        const T t_urho = d_dx.quo(dX * lo.rho * u    - (a[P0][1] - a[P1][1]));
+        const T t_vrho = d_dx.quo(dX * lo.rho * v    - (a[P0][2] - a[P1][2]));
+        const T t_Erho = d_dx.quo(dX * lo.rho * lo.E - (a[P0][3] - a[P1][3]));
         Out4<T> o;
         o.rho = t_rho;
-        const T un = t_urho / t_rho, vn = t_vrho / t_rho;
+        const Den d_rho(t_rho);
+        const T un = d_rho.quo(t_urho), vn = d_rho.quo(t_vrho);
         o.ua = Y_AXIS ? vn : un;
         o.ut = Y_AXIS ? un : vn;
-        o.E = t_Erho / t_rho;
+        o.E = d_rho.quo(t_Erho);
         return o;
     }
 };

@@ -103,15 +103,13 @@ struct SpatialSweep {
     __device__ __forceinline__ void run_exact(const S_& rho, const S_& ua, const S_& ut, const S_& E,
                                               S_& o_rho, S_& o_u, S_& o_v, S_& o_E, S_& p, S_& cs) const
     {
+        using Den = xct::Den<T>;       // correctly rounded quotients, shared denominators (sweep_pipeline.hpp)
+        const Den d_dx(dx);
         S_ rc;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (EOS == ARMON_EOS_BIZARRIUM) {
-                T g_unused;
-                phys::bizarrium<false>(rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k], g_unused);
-            } else {
-                phys::perfect_gas(gamma, rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k]);
-            }
+            if (EOS == ARMON_EOS_BIZARRIUM) xct::bizarrium(rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k]);
+            else xct::perfect_gas(gamma, rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k]);
             rc.v[k] = rho[k] * cs[k];
         }
         // first-order solve on the low side of each cell (ref src/riemann_schemes.jl:21-30)
@@ -120,8 +118,9 @@ struct SpatialSweep {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const T rc_l = rcL[k], rc_r = rc[k];
-            gus.v[k] = (rc_l * uL[k] + rc_r * ua[k] + (pL[k] - p[k])) / (rc_l + rc_r);
-            gps.v[k] = (rc_r * pL[k] + rc_l * p[k] + rc_l * rc_r * (uL[k] - ua[k])) / (rc_l + rc_r);
+            const Den d(rc_l + rc_r);
+            gus.v[k] = d.quo(rc_l * uL[k] + rc_r * ua[k] + (pL[k] - p[k]));
+            gps.v[k] = d.quo(rc_r * pL[k] + rc_l * p[k] + rc_l * rc_r * (uL[k] - ua[k]));
         }
         S_ fus, fps;
         if (S == 1) {
@@ -130,14 +129,14 @@ struct SpatialSweep {
             const Sh gusL = left_of(gus), gpsL = left_of(gps), gusR = right_of(gus), gpsR = right_of(gps);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const T r_um = phys::limiter<LIM>((gusR[k] - ua[k]) / (gus[k] - uL[k] + T(1e-6)));
-                const T r_pm = phys::limiter<LIM>((gpsR[k] - p[k]) / (gps[k] - pL[k] + T(1e-6)));
-                const T r_up = phys::limiter<LIM>((uL[k] - gusL[k]) / (ua[k] - gus[k] + T(1e-6)));
-                const T r_pp = phys::limiter<LIM>((pL[k] - gpsL[k]) / (p[k] - gps[k] + T(1e-6)));
+                const T r_um = phys::limiter<LIM>(Den(gus[k] - uL[k] + T(1e-6)).quo(gusR[k] - ua[k]));
+                const T r_pm = phys::limiter<LIM>(Den(gps[k] - pL[k] + T(1e-6)).quo(gpsR[k] - p[k]));
+                const T r_up = phys::limiter<LIM>(Den(ua[k] - gus[k] + T(1e-6)).quo(uL[k] - gusL[k]));
+                const T r_pp = phys::limiter<LIM>(Den(p[k] - gps[k] + T(1e-6)).quo(pL[k] - gpsL[k]));
                 const T dm_l = rhoL[k] * dx;
                 const T dm_r = rho[k] * dx;
                 const T Dm = (dm_l + dm_r) / 2;
-                const T theta = T(0.5) * (1 - (rcL[k] + rc[k]) / 2 * (dt / Dm));
+                const T theta = T(0.5) * (1 - (rcL[k] + rc[k]) / 2 * Den(Dm).quo(dt));
                 fus.v[k] = gus[k] + theta * (r_up * (ua[k] - gus[k]) - r_um * (gus[k] - uL[k]));
                 fps.v[k] = gps[k] + theta * (r_pp * (p[k] - gps[k]) - r_pm * (gps[k] - pL[k]));
             }
@@ -152,9 +151,10 @@ struct SpatialSweep {
         for (int k = 0; k < K; k++) {
             const T dm = rho[k] * dx;
             dxl.v[k] = dx + dt * (fusR[k] - fus[k]);
-            l_rho.v[k] = dm / dxl[k];
-            l_ua.v[k] = ua[k] + dt / dm * (fps[k] - fpsR[k]);
-            l_E.v[k] = E[k] + dt / dm * (fps[k] * fus[k] - fpsR[k] * fusR[k]);
+            l_rho.v[k] = Den(dxl[k]).quo(dm);
+            const T dt_dm = Den(dm).quo(dt);
+            l_ua.v[k] = ua[k] + dt_dm * (fps[k] - fpsR[k]);
+            l_E.v[k] = E[k] + dt_dm * (fps[k] * fus[k] - fpsR[k] * fusR[k]);
             q_ua.v[k] = l_rho[k] * l_ua[k];
             q_ut.v[k] = l_rho[k] * ut[k];
             q_E.v[k] = l_rho[k] * l_E[k];
@@ -168,8 +168,8 @@ struct SpatialSweep {
             S_ s0, s1, s2, s3;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const T r_m = (2 * dxl[k]) / (dxl[k] + dxlL[k]);
-                const T r_p = (2 * dxl[k]) / (dxl[k] + dxlR[k]);
+                const T r_m = Den(dxl[k] + dxlL[k]).quo(2 * dxl[k]);
+                const T r_p = Den(dxl[k] + dxlR[k]).quo(2 * dxl[k]);
                 s0.v[k] = phys::slope_minmod(rL[k], l_rho[k], rR[k], r_m, r_p);
                 s1.v[k] = phys::slope_minmod(quL[k], q_ua[k], quR[k], r_m, r_p);
                 s2.v[k] = phys::slope_minmod(qvL[k], q_ut[k], qvR[k], r_m, r_p);
@@ -182,7 +182,7 @@ struct SpatialSweep {
                 const T disp = dt * fus[k];
                 const bool up = disp > 0;
                 const T Dxe = up ? -(dx - dt * fusL[k]) : (dx + dt * fusR[k]);
-                const T lf = Dxe / (2 * (up ? dxlL[k] : dxl[k]));
+                const T lf = Den(2 * (up ? dxlL[k] : dxl[k])).quo(Dxe);
                 a0.v[k] = disp * ((up ? rL[k] : l_rho[k]) - (up ? s0L[k] : s0[k]) * lf);
                 a1.v[k] = disp * ((up ? quL[k] : q_ua[k]) - (up ? s1L[k] : s1[k]) * lf);
                 a2.v[k] = disp * ((up ? qvL[k] : q_ut[k]) - (up ? s2L[k] : s2[k]) * lf);
@@ -204,14 +204,15 @@ struct SpatialSweep {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const T dX = dxl[k];
-            const T t_rho  = (dX * l_rho[k]           - (a0R[k] - a0[k])) / dx;
-            const T t_urho = (dX * l_rho[k] * l_ua[k] - (a1R[k] - a1[k])) / dx;
-            const T t_vrho = (dX * l_rho[k] * ut[k]   - (a2R[k] - a2[k])) / dx;
-            const T t_Erho = (dX * l_rho[k] * l_E[k]  - (a3R[k] - a3[k])) / dx;
+            const T t_rho  = d_dx.quo(dX * l_rho[k]           - (a0R[k] - a0[k]));
+            const T t_urho = d_dx.quo(dX * l_rho[k] * l_ua[k] - (a1R[k] - a1[k]));
+            const T t_vrho = d_dx.quo(dX * l_rho[k] * ut[k]   - (a2R[k] - a2[k]));
+            const T t_Erho = d_dx.quo(dX * l_rho[k] * l_E[k]  - (a3R[k] - a3[k]));
+            const Den d_rho(t_rho);
             o_rho.v[k] = t_rho;
-            o_u.v[k] = t_urho / t_rho;
-            o_v.v[k] = t_vrho / t_rho;
-            o_E.v[k] = t_Erho / t_rho;
+            o_u.v[k] = d_rho.quo(t_urho);
+            o_v.v[k] = d_rho.quo(t_vrho);
+            o_E.v[k] = d_rho.quo(t_Erho);
         }
     }
 

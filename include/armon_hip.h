@@ -297,6 +297,15 @@ typedef struct {
 
 ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
 
+/* Whole cycle in one launch (Sequential splitting: X sweep, then Y sweep — ref src/solver.jl:300-316 executed twice)
+ * over one block: reads (rho,u,v,E) of x_desc->*_in ONCE and writes y_desc->*_out ONCE; the state between the two
+ * sweeps stays in registers (32 B read + 32 B written per cell per CYCLE). x_desc gives the X sweep's dt, dx and
+ * boundary; y_desc the Y sweep's, plus p_out (EOS pressure of the state before the Y sweep), dt_cfl_out and an
+ * optional row range out_lo/out_hi. Results are the bits of armon_hip_sweep(x_desc) followed by armon_hip_sweep(y_desc).
+ * fp64, GAD + minmod + euler_2nd, perfect gas, tuned arithmetic only; a block whose Y sides are remote cannot use it
+ * (the rows received from a neighbour would have to be X-swept first). No reference counterpart. */
+ARMON_API int armon_hip_cycle_xy(armon_ctx*, const armon_sweep_desc* x_desc, const armon_sweep_desc* y_desc);
+
 /* Placement of the 8 vectors a fused sweep streams (4 read + 4 written). On MI355X the same sweeps run 10-20 %
  * apart depending on where these vectors sit in HBM relative to each other (back-to-back allocations end up at a
  * regular physical spacing that makes the 8 streams collide on channels/banks), so a host
@@ -314,7 +323,8 @@ ARMON_API int armon_hip_tune_placement(armon_ctx*, const armon_sweep_desc* x_des
 /* The same choice for a pool that holds NO state yet — call it BEFORE init_test: nothing has to be parked or restored,
  * so the only transient memory is the caller's own spare vectors (n_pool - 8 of them). Candidates are timed on a uniform
  * state the call writes itself (every vector of the pool is overwritten); the search stops early once two draws lie
- * within `tolerance` (e.g. 0.01; 0 = never) of the best seen, after at most `tries`. picks[role] as above (roles 0..3:
+ * within `tolerance` (e.g. 0.01; 0 = never) of the best seen and a draw >= 3 % slower has been seen too, after at most
+ * `tries`. picks[role] as above (roles 0..3:
  * where init_test should put rho,u,v,E; 4..7: their ping-pong partners); *tries_done (nullable) = draws timed. */
 ARMON_API int armon_hip_choose_placement(armon_ctx*, const armon_sweep_desc* x_desc, const armon_sweep_desc* y_desc,
         void* const* pool, int n_pool, size_t bytes, int tries, double tolerance, int picks[8], double* times_ms,
