@@ -7,6 +7,7 @@
 // reference's 1-D ndrange + divrem (ref src/generic_kernel.jl:784-791).
 #include "common.hpp"
 #include "physics.hpp"
+#include "sweep_spatial.hpp"   // wavefront shifts (from_prev_lane / from_next_lane)
 
 using namespace armon;
 
@@ -16,6 +17,10 @@ __device__ __forceinline__ int64_t row_base(const armon_range& r, int64_t j)
 {
     return r.col_start + j * r.col_step + r.row_start;
 }
+
+// Outputs that the next kernel re-reads only after 2+ GB of other traffic (fluxes, advected quantities): streaming
+// stores, so that they do not displace the neighbour rows the stencils DO re-read from L2.
+template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
 #define ARMON_FOR_RANGE(r, i)                                                         \
     const int64_t k_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;                 \
@@ -94,6 +99,87 @@ k_acoustic_GAD(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us,
     }
 }
 
+// The reference's kernel above solves every interface three times (once as "its own", twice as a neighbour's:
+// ref src/riemann_schemes.jl:63-80). The two forms below compute the same values from the same operands — bit for bit
+// the same results — but solve each interface ONCE and hand the solutions to the neighbours:
+//  * sweep along x (s == 1): lanes along x, a wave covers 64 consecutive cells of which the two outer ones are halo
+//    lanes (they only contribute their interface solution); neighbours' cells and solutions come from DPP wavefront
+//    shifts. 62 fluxes per 64 solves.
+//  * sweep along y (s == row pitch of the range): lane ↔ column, each thread walks kGadRows rows with a rolling
+//    window of the last two cells and three solutions. kGadRows fluxes per kGadRows + 2 solves.
+// No cell outside the reference's own stencil [i - 2s, i + s] of the range is read.
+constexpr int kGadValid = 62;
+constexpr int kGadRows = 32;
+
+template <int LIM, typename T>
+__global__ void __launch_bounds__(kBlock)
+k_acoustic_GAD_x(armon_range r, T dt, T dx, T* __restrict__ us, T* __restrict__ ps, const T* __restrict__ rho,
+                 const T* __restrict__ u, const T* __restrict__ p, const T* __restrict__ c)
+{
+    using fused::from_next_lane;
+    using fused::from_prev_lane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t k = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kGadValid + lane - 1;   // lanes 0 and 63: halo
+    const bool has_cell = k >= -1 && k <= r.row_len;           // the halo lanes may sit one cell outside the row
+    const bool stores = lane >= 1 && lane <= kGadValid && k < r.row_len;
+    if (((int64_t)blockIdx.x * (kBlock / 64) + wave) * kGadValid >= r.row_len) return;      // whole wave past the row
+    for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
+        const int64_t i = row_base(r, j) + k;
+        T rho_i = 1, c_i = 1, u_i = 0, p_i = 1;
+        if (has_cell) { rho_i = rho[i]; c_i = c[i]; u_i = u[i]; p_i = p[i]; }
+        T rho_m = from_prev_lane(rho_i), c_m = from_prev_lane(c_i), u_m = from_prev_lane(u_i), p_m = from_prev_lane(p_i);
+        if (lane == 0) {                                        // no lane to the left: its cell i - 1 from memory
+            rho_m = 1; c_m = 1; u_m = 0; p_m = 1;
+            if (has_cell) { rho_m = rho[i - 1]; c_m = c[i - 1]; u_m = u[i - 1]; p_m = p[i - 1]; }
+        }
+        T us_0, ps_0;
+        phys::godunov(rho_i, rho_m, c_i, c_m, u_i, u_m, p_i, p_m, us_0, ps_0);        // interface i | i-1, once
+        const T us_m = from_prev_lane(us_0), ps_m = from_prev_lane(ps_0);
+        const T us_p = from_next_lane(us_0), ps_p = from_next_lane(ps_0);
+        T a, b;
+        phys::gad_flux<LIM>(dt, dx, rho_m, c_m, u_m, p_m, rho_i, c_i, u_i, p_i, us_m, ps_m, us_0, ps_0, us_p, ps_p, a, b);
+        if (stores) {
+            st_stream(us + i, a);
+            st_stream(ps + i, b);
+        }
+    }
+}
+
+template <int LIM, typename T>
+__global__ void __launch_bounds__(kBlock)
+k_acoustic_GAD_y(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us, T* __restrict__ ps, const T* __restrict__ rho,
+                 const T* __restrict__ u, const T* __restrict__ p, const T* __restrict__ c)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= r.row_len) return;
+    const int64_t j0 = (int64_t)blockIdx.y * kGadRows;
+    const int64_t j1 = (j0 + kGadRows < r.col_len) ? j0 + kGadRows : r.col_len;
+    int64_t i = row_base(r, j0) + k;
+    // cells j0-2, j0-1, j0 and the solutions of interfaces j0-1 and j0
+    T rho_mm = rho[i - 2 * s], c_mm = c[i - 2 * s], u_mm = u[i - 2 * s], p_mm = p[i - 2 * s];
+    T rho_m = rho[i - s], c_m = c[i - s], u_m = u[i - s], p_m = p[i - s];
+    T rho_i = rho[i], c_i = c[i], u_i = u[i], p_i = p[i];
+    T us_m, ps_m, us_0, ps_0;
+    phys::godunov(rho_m, rho_mm, c_m, c_mm, u_m, u_mm, p_m, p_mm, us_m, ps_m);
+    phys::godunov(rho_i, rho_m, c_i, c_m, u_i, u_m, p_i, p_m, us_0, ps_0);
+    T rho_p = rho[i + s], c_p = c[i + s], u_p = u[i + s], p_p = p[i + s];               // row j0 + 1
+    for (int64_t j = j0; j < j1; j++, i += s) {
+        // row j + 2 is requested before row j + 1 is consumed (the loads of a step overlap the arithmetic of the previous one)
+        const int64_t in = (j + 1 < j1) ? i + 2 * s : i + s;
+        const T rho_n = rho[in], c_n = c[in], u_n = u[in], p_n = p[in];
+        T us_p, ps_p, a, b;
+        phys::godunov(rho_p, rho_i, c_p, c_i, u_p, u_i, p_p, p_i, us_p, ps_p);         // interface j+1 | j, once
+        phys::gad_flux<LIM>(dt, dx, rho_m, c_m, u_m, p_m, rho_i, c_i, u_i, p_i, us_m, ps_m, us_0, ps_0, us_p, ps_p, a, b);
+        st_stream(us + i, a);
+        st_stream(ps + i, b);
+        rho_m = rho_i; c_m = c_i; u_m = u_i; p_m = p_i;
+        rho_i = rho_p; c_i = c_p; u_i = u_p; p_i = p_p;
+        rho_p = rho_n; c_p = c_n; u_p = u_n; p_p = p_n;
+        us_m = us_0; ps_m = ps_0;
+        us_0 = us_p; ps_0 = ps_p;
+    }
+}
+
 // ---- a6: cell_update! (ref src/kernels.jl:58-68) ---------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -154,8 +240,8 @@ k_advection_second_order(armon_range r, int64_t s, T dx, T dt,
         T Dxl_m = dx + dt * (us[d] - us[d - s]);
         T Dxl   = dx + dt * (us[d + s] - us[d]);
         T Dxl_p = dx + dt * (us[d + 2 * s] - us[d + s]);
-        T r_m = (2 * Dxl) / (Dxl + Dxl_m);
-        T r_p = (2 * Dxl) / (Dxl + Dxl_p);
+        T r_m = xct::Den<T>(Dxl + Dxl_m).quo(2 * Dxl);
+        T r_p = xct::Den<T>(Dxl + Dxl_p).quo(2 * Dxl);
 
         T rm = rho[d - s], r0 = rho[d], rp = rho[d + s];
         T sl_rho  = phys::slope_minmod(rm, r0, rp, r_m, r_p);
@@ -163,11 +249,123 @@ k_advection_second_order(armon_range r, int64_t s, T dx, T dt,
         T sl_vrho = phys::slope_minmod(rm * v[d - s], r0 * v[d], rp * v[d + s], r_m, r_p);
         T sl_Erho = phys::slope_minmod(rm * E[d - s], r0 * E[d], rp * E[d + s], r_m, r_p);
 
-        T length_factor = Dxe / (2 * Dxl);
+        T length_factor = xct::Den<T>(2 * Dxl).quo(Dxe);
         a_rho[is]  = disp * (r0        - sl_rho  * length_factor);
         a_urho[is] = disp * (r0 * u[d] - sl_urho * length_factor);
         a_vrho[is] = disp * (r0 * v[d] - sl_vrho * length_factor);
         a_Erho[is] = disp * (r0 * E[d] - sl_Erho * length_factor);
+    }
+}
+
+// The reference's kernel above gathers, per interface, three deformed lengths, the limited slopes and the products
+// ρu, ρv, ρE of the DONOR cell and its two neighbours (17 loads, ref src/projection_schemes.jl:92-124). The deformed
+// length Δx(c) = dx + dt·(uˢ[c+s] − uˢ[c]), the products and the slopes are cell-centred quantities: the two forms
+// below evaluate them once per cell — the same expressions on the same operands, hence the same bits — and let the
+// interface pick its donor's:
+//  * sweep along x: lanes along x (a wave covers 64 cells, 60 interfaces: two halo lanes on each side), neighbours by
+//    DPP wavefront shifts — 5 loads per lane;
+//  * sweep along y: lane ↔ column, kAdvRows rows per thread with rolling windows — 5 loads per row.
+// No cell outside the reference's own stencil (uˢ @ is-2s..is+2s; ρ,u,v,E @ is-2s..is+s) is read.
+constexpr int kAdvValid = 60;
+constexpr int kAdvRows = 32;
+
+template <typename T> struct adv_cell { T rho, qu, qv, qE; };
+
+template <typename T>
+__device__ __forceinline__ adv_cell<T> adv_load(const T* rho, const T* u, const T* v, const T* E, int64_t i)
+{
+    const T r = rho[i];
+    return adv_cell<T>{r, r * u[i], r * v[i], r * E[i]};
+}
+
+// limited slopes of cell C between its neighbours L and R (ref :105-116)
+template <typename T>
+__device__ __forceinline__ adv_cell<T> adv_slopes(const adv_cell<T>& L, const adv_cell<T>& C, const adv_cell<T>& R,
+                                                  T D_L, T D_C, T D_R)
+{
+    const T r_m = xct::Den<T>(D_C + D_L).quo(2 * D_C);
+    const T r_p = xct::Den<T>(D_C + D_R).quo(2 * D_C);
+    return adv_cell<T>{phys::slope_minmod(L.rho, C.rho, R.rho, r_m, r_p), phys::slope_minmod(L.qu, C.qu, R.qu, r_m, r_p),
+                       phys::slope_minmod(L.qv, C.qv, R.qv, r_m, r_p), phys::slope_minmod(L.qE, C.qE, R.qE, r_m, r_p)};
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_advection_second_order_x(armon_range r, T dx, T dt, const T* __restrict__ us, const T* __restrict__ rho,
+                           const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ E,
+                           T* __restrict__ a_rho, T* __restrict__ a_urho, T* __restrict__ a_vrho, T* __restrict__ a_Erho)
+{
+    using fused::from_next_lane;
+    using fused::from_prev_lane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kAdvValid;      // first interface of this wave
+    if (w0 >= r.row_len) return;
+    const int64_t k = w0 + lane - 2;                                                  // lanes 0,1 and 62,63: halo
+    const bool has_us = k >= -2 && k <= r.row_len + 1;
+    const bool has_cell = k >= -2 && k <= r.row_len;                                  // ρ,u,v,E are read up to is + s only
+    const bool stores = lane >= 2 && lane < 2 + kAdvValid && k < r.row_len;
+    for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
+        const int64_t i = row_base(r, j) + k;
+        const T us_c = has_us ? us[i] : T(0);
+        const adv_cell<T> C = has_cell ? adv_load(rho, u, v, E, i) : adv_cell<T>{1, 0, 0, 1};
+        const T us_L = from_prev_lane(us_c), us_R = from_next_lane(us_c);
+        const T D_C = dx + dt * (us_R - us_c);
+        const T D_L = from_prev_lane(D_C), D_R = from_next_lane(D_C);
+        const adv_cell<T> L{from_prev_lane(C.rho), from_prev_lane(C.qu), from_prev_lane(C.qv), from_prev_lane(C.qE)};
+        const adv_cell<T> R{from_next_lane(C.rho), from_next_lane(C.qu), from_next_lane(C.qv), from_next_lane(C.qE)};
+        const adv_cell<T> sl = adv_slopes(L, C, R, D_L, D_C, D_R);
+        const adv_cell<T> slL{from_prev_lane(sl.rho), from_prev_lane(sl.qu), from_prev_lane(sl.qv), from_prev_lane(sl.qE)};
+        const T disp = dt * us_c;
+        const bool up = disp > 0;
+        const T Dxe = up ? -(dx - dt * us_L) : (dx + dt * us_R);
+        const T lf = xct::Den<T>(2 * (up ? D_L : D_C)).quo(Dxe);
+        if (stores) {
+            st_stream(a_rho + i,  disp * ((up ? L.rho : C.rho) - (up ? slL.rho : sl.rho) * lf));
+            st_stream(a_urho + i, disp * ((up ? L.qu : C.qu) - (up ? slL.qu : sl.qu) * lf));
+            st_stream(a_vrho + i, disp * ((up ? L.qv : C.qv) - (up ? slL.qv : sl.qv) * lf));
+            st_stream(a_Erho + i, disp * ((up ? L.qE : C.qE) - (up ? slL.qE : sl.qE) * lf));
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_advection_second_order_y(armon_range r, int64_t s, T dx, T dt, const T* __restrict__ us, const T* __restrict__ rho,
+                           const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ E,
+                           T* __restrict__ a_rho, T* __restrict__ a_urho, T* __restrict__ a_vrho, T* __restrict__ a_Erho)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= r.row_len) return;
+    const int64_t j0 = (int64_t)blockIdx.y * kAdvRows;
+    const int64_t j1 = (j0 + kAdvRows < r.col_len) ? j0 + kAdvRows : r.col_len;
+    int64_t i = row_base(r, j0) + k;
+    T us_L = us[i - s], us_C = us[i], us_R = us[i + s];
+    const T us_LL = us[i - 2 * s];
+    adv_cell<T> L = adv_load(rho, u, v, E, i - s), C = adv_load(rho, u, v, E, i);
+    T D_L = dx + dt * (us_C - us_L), D_C = dx + dt * (us_R - us_C);
+    adv_cell<T> slL = adv_slopes(adv_load(rho, u, v, E, i - 2 * s), L, C, dx + dt * (us_L - us_LL), D_L, D_C);
+    T us_RR = us[i + 2 * s];                                                            // rows j0 + 2 / j0 + 1
+    T rn = rho[i + s], un = u[i + s], vn = v[i + s], En = E[i + s];
+    for (int64_t j = j0; j < j1; j++, i += s) {
+        const adv_cell<T> R{rn, rn * un, rn * vn, rn * En};
+        const T D_R = dx + dt * (us_RR - us_R);
+        // the next row's operands are requested before this row's arithmetic
+        const int64_t in = (j + 1 < j1) ? i + 2 * s : i + s;
+        const T us_n = us[in + s];
+        rn = rho[in]; un = u[in]; vn = v[in]; En = E[in];
+        const adv_cell<T> sl = adv_slopes(L, C, R, D_L, D_C, D_R);
+        const T disp = dt * us_C;
+        const bool up = disp > 0;
+        const T Dxe = up ? -(dx - dt * us_L) : (dx + dt * us_R);
+        const T lf = xct::Den<T>(2 * (up ? D_L : D_C)).quo(Dxe);
+        st_stream(a_rho + i,  disp * ((up ? L.rho : C.rho) - (up ? slL.rho : sl.rho) * lf));
+        st_stream(a_urho + i, disp * ((up ? L.qu : C.qu) - (up ? slL.qu : sl.qu) * lf));
+        st_stream(a_vrho + i, disp * ((up ? L.qv : C.qv) - (up ? slL.qv : sl.qv) * lf));
+        st_stream(a_Erho + i, disp * ((up ? L.qE : C.qE) - (up ? slL.qE : sl.qE) * lf));
+        L = C; C = R;
+        D_L = D_C; D_C = D_R;
+        us_L = us_C; us_C = us_R; us_R = us_RR; us_RR = us_n;
+        slL = sl;
     }
 }
 
@@ -361,19 +559,28 @@ int acoustic_GAD_impl(armon_ctx* ctx, armon_range r, int64_t s, T dt, T dx, T* u
     ARMON_REQUIRE(s > 0, "stride must be positive");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
+    // form of the kernel: 1 = lanes along the sweep (s == 1), 2 = march along the sweep (s == row pitch), 0 = the
+    // reference's own shape (any other stride)
+    const int form = (s == 1) ? 1 : ((s == r.col_step && r.col_len > 1) ? 2 : 0);
+    if (form == 1) grid.x = (unsigned)(((r.row_len + kGadValid - 1) / kGadValid + kBlock / 64 - 1) / (kBlock / 64));   // waves of 62 fluxes
+    if (form == 2) grid.y = (unsigned)((r.col_len + kGadRows - 1) / kGadRows);
+#define ARMON_GAD_LAUNCH(LIM)                                                                                              \
+    do {                                                                                                                   \
+        if (form == 1)                                                                                                     \
+            hipLaunchKernelGGL((k_acoustic_GAD_x<LIM, T>), grid, block, 0, ctx->stream, r, dt, dx, us, ps, rho, ua, p, c);  \
+        else if (form == 2)                                                                                                \
+            hipLaunchKernelGGL((k_acoustic_GAD_y<LIM, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c); \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_acoustic_GAD<LIM, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c); \
+    } while (0)
     switch (limiter) {
-    case ARMON_LIMITER_NONE:
-        hipLaunchKernelGGL((k_acoustic_GAD<ARMON_LIMITER_NONE, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
-        break;
-    case ARMON_LIMITER_MINMOD:
-        hipLaunchKernelGGL((k_acoustic_GAD<ARMON_LIMITER_MINMOD, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
-        break;
-    case ARMON_LIMITER_SUPERBEE:
-        hipLaunchKernelGGL((k_acoustic_GAD<ARMON_LIMITER_SUPERBEE, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c);
-        break;
+    case ARMON_LIMITER_NONE: ARMON_GAD_LAUNCH(ARMON_LIMITER_NONE); break;
+    case ARMON_LIMITER_MINMOD: ARMON_GAD_LAUNCH(ARMON_LIMITER_MINMOD); break;
+    case ARMON_LIMITER_SUPERBEE: ARMON_GAD_LAUNCH(ARMON_LIMITER_SUPERBEE); break;
     default:
         ARMON_REQUIRE(false, "unknown limiter tag %d", limiter);
     }
+#undef ARMON_GAD_LAUNCH
     return check_launch("acoustic_GAD");
 }
 
@@ -412,8 +619,18 @@ int advection_second_order_impl(armon_ctx* ctx, armon_range r, int64_t s, T dx, 
     ARMON_REQUIRE(s > 0, "stride must be positive");
     dim3 grid, block;
     range_grid(r, 1, grid, block);
-    hipLaunchKernelGGL(k_advection_second_order<T>, grid, block, 0, ctx->stream, r, s, dx, dt, us, rho, u,
-                       v, E, a_rho, a_urho, a_vrho, a_Erho);
+    if (s == 1) {                                         // lanes along the sweep: 60 interfaces per wave
+        grid.x = (unsigned)(((r.row_len + kAdvValid - 1) / kAdvValid + kBlock / 64 - 1) / (kBlock / 64));
+        hipLaunchKernelGGL(k_advection_second_order_x<T>, grid, block, 0, ctx->stream, r, dx, dt, us, rho, u,
+                           v, E, a_rho, a_urho, a_vrho, a_Erho);
+    } else if (s == r.col_step && r.col_len > 1) {        // march along the sweep
+        grid.y = (unsigned)((r.col_len + kAdvRows - 1) / kAdvRows);
+        hipLaunchKernelGGL(k_advection_second_order_y<T>, grid, block, 0, ctx->stream, r, s, dx, dt, us, rho, u,
+                           v, E, a_rho, a_urho, a_vrho, a_Erho);
+    } else {
+        hipLaunchKernelGGL(k_advection_second_order<T>, grid, block, 0, ctx->stream, r, s, dx, dt, us, rho, u,
+                           v, E, a_rho, a_urho, a_vrho, a_Erho);
+    }
     return check_launch("advection_second_order");
 }
 

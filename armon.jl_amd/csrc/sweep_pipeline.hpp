@@ -42,117 +42,6 @@ struct PipeTraits {
 };
 
 // ======================================================================================================
-// Correctly rounded division and square root at speed (exact flavour)
-// ======================================================================================================
-// The compiler's IEEE a/b is v_div_scale ×2, v_rcp_f64, two Newton steps, quotient, remainder, v_div_fmas,
-// v_div_fixup: 11 instructions, 20 times per cell. The scale / fix-up instructions only act when an operand or
-// the quotient leaves ~2^±500 (or is 0, inf, NaN); everything the solver divides is within 1e±30, and there the
-// remaining operations — reproduced below in the same order — give the same, correctly rounded bits (asserted by
-// every bit-parity test against the oracle, which divides with the CPU's IEEE instruction). A prepared denominator
-// (reciprocal refined once: 5 instructions) then serves every quotient that shares it for 3 instructions each:
-// the two Godunov quotients (ref src/riemann_schemes.jl:27-28), the three u,v,E of the projection, its four /dx,
-// the two dt/dm of the cell update, consecutive slope ratios.
-namespace xct {
-
-template <typename T> struct Den;
-
-// fp32: the compiler's own expansion (it toggles the denormal mode around its FMAs; nothing to share cheaply)
-template <> struct Den<float> {
-    float b;
-    __device__ __forceinline__ Den() : b(1.f) {}
-    __device__ __forceinline__ explicit Den(float b_) : b(b_) {}
-    __device__ __forceinline__ float quo(float a) const { return a / b; }
-    __device__ __forceinline__ Den twice() const { return Den(2.f * b); }
-};
-
-#ifdef ARMON_XCT_PLAIN   // A/B builds: the compiler's IEEE expansion everywhere (tools/build_variant.sh)
-template <> struct Den<double> {
-    double b;
-    __device__ __forceinline__ Den() : b(1.) {}
-    __device__ __forceinline__ explicit Den(double b_) : b(b_) {}
-    __device__ __forceinline__ double quo(double a) const { return a / b; }
-    __device__ __forceinline__ Den twice() const { return Den(2. * b); }
-};
-__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
-#else
-template <> struct Den<double> {
-    double b, r;                                     // denominator and its reciprocal (≤ 1 ulp)
-    __device__ __forceinline__ Den() : b(1.), r(1.) {}
-    __device__ __forceinline__ explicit Den(double b_) : b(b_)
-    {
-        double y = __builtin_amdgcn_rcp(b_);
-        double e = __builtin_fma(-b_, y, 1.0);
-        y = __builtin_fma(y, e, y);
-        e = __builtin_fma(-b_, y, 1.0);
-        r = __builtin_fma(y, e, y);
-    }
-    __device__ __forceinline__ double quo(double a) const       // a / b
-    {
-        const double q = a * r;
-        const double rem = __builtin_fma(-b, q, a);
-        return __builtin_fma(rem, r, q);
-    }
-    __device__ __forceinline__ Den twice() const                // the denominator 2·b (exact scaling)
-    {
-        Den d;
-        d.b = 2. * b;
-        d.r = 0.5 * r;
-        return d;
-    }
-};
-
-__device__ __forceinline__ double sqrt_(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = y * 0.5;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    return (x == 0.) ? x : g;
-}
-#endif
-__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
-
-// ref src/kernels.jl:4-13
-template <typename T>
-__device__ __forceinline__ void perfect_gas(T gamma, T rho, T E, T u, T v, T& p, T& c)
-{
-    const T e = E - T(0.5) * (u * u + v * v);
-    p = (gamma - T(1.)) * rho * e;
-    c = sqrt_(Den<T>(rho).quo(gamma * p));
-}
-
-// ref src/kernels.jl:16-55 without f3 / pk0second / g (never read by the sweep)
-template <typename T>
-__device__ __forceinline__ void bizarrium(T rho, T E, T u, T v, T& p, T& c)
-{
-    const T rho0 = T(10000.), K0 = T(1e+11), Cv0 = T(1000.), T0 = T(300.), eps0 = T(0.), G0 = T(1.5), s = T(1.5);
-    const T q = T(-42080895. / 14941154.), rr = T(727668333. / 149411540.);
-    const Den<T> d_rho(rho);
-    T x = Den<T>(rho0).quo(rho) - 1;
-    T G = G0 * (1 - d_rho.quo(rho0));
-    T x2 = x * x, x3 = x * x * x;
-    T opx = 1 + x, opx2 = opx * opx, opx3 = opx * opx * opx;
-    const Den<T> d_sx(1 - s * x);
-    T f0 = d_sx.quo(1 + (s / 3 - 2) * x + q * x2 + rr * x3);
-    T f1 = d_sx.quo(s / 3 - 2 + 2 * q * x + 3 * rr * x2 + s * f0);
-    T f2 = d_sx.quo(2 * q + 6 * rr * x + 2 * s * f1);
-    T epsk0 = eps0 - Cv0 * T0 * (1 + G) + T(0.5) * (K0 / rho0) * x2 * f0;
-    T pk0 = -Cv0 * T0 * G0 * rho0 + T(0.5) * K0 * x * opx2 * (2 * f0 + x * f1);
-    T pk0prime = -T(0.5) * K0 * opx3 * rho0 *
-                 (2 * (1 + 3 * x) * f0 + 2 * x * (2 + 3 * x) * f1 + x2 * opx * f2);
-    T e = E - T(0.5) * (u * u + v * v);
-    p = pk0 + G0 * rho0 * (e - epsk0);
-    c = d_rho.quo(sqrt_(G0 * rho0 * (p - pk0) - pk0prime));
-}
-
-}  // namespace xct
-
-// ======================================================================================================
 // EXACT pipeline
 // ======================================================================================================
 template <int SCHEME, int LIM, int PROJ, int EOS, typename T = double>
@@ -219,8 +108,12 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         T p, cs;
         {
             const T u = Y_AXIS ? c0.ut : c0.ua, v = Y_AXIS ? c0.ua : c0.ut;
-            if (EOS == ARMON_EOS_BIZARRIUM) xct::bizarrium(c0.rho, c0.E, u, v, p, cs);
-            else xct::perfect_gas(gamma, c0.rho, c0.E, u, v, p, cs);
+            if (EOS == ARMON_EOS_BIZARRIUM) {
+                T g_unused;
+                phys::bizarrium<false>(c0.rho, c0.E, u, v, p, cs, g_unused);
+            } else {
+                phys::perfect_gas(gamma, c0.rho, c0.E, u, v, p, cs);
+            }
         }
         p_j = p;
         c_j = cs;

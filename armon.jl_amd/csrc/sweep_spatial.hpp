@@ -108,8 +108,12 @@ struct SpatialSweep {
         S_ rc;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (EOS == ARMON_EOS_BIZARRIUM) xct::bizarrium(rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k]);
-            else xct::perfect_gas(gamma, rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k]);
+            if (EOS == ARMON_EOS_BIZARRIUM) {
+                T g_unused;
+                phys::bizarrium<false>(rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k], g_unused);
+            } else {
+                phys::perfect_gas(gamma, rho[k], E[k], ua[k], ut[k], p.v[k], cs.v[k]);
+            }
             rc.v[k] = rho[k] * cs[k];
         }
         // first-order solve on the low side of each cell (ref src/riemann_schemes.jl:21-30)

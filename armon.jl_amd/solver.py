@@ -155,9 +155,9 @@ class BlockGrid:
 
         ``keep_state=False`` (what ``init_test`` does, BEFORE it writes the initial condition):
         ``armon_hip_choose_placement`` — the vectors hold nothing yet, candidates are timed on a uniform state, the
-        search stops once two draws lie within 1 % of the best; transient memory = the ``spare`` (default 4) vectors
-        only, 8.6 GB at 16384². ``keep_state=True``: ``armon_hip_tune_placement`` moves a LIVE state around (4 more
-        vectors park it meanwhile; default 8 spares). ~20 ms per try, outside any timed region.
+        search may stop after 8 draws once two of them lie within 1 % of the best; transient memory = the 8 ``spare``
+        vectors only (17 GB at 16384²: with 4 spares one process in three finds no good placement at all in 12 draws).
+        ``keep_state=True``: ``armon_hip_tune_placement`` moves a LIVE state around (4 more vectors park it meanwhile). ~20 ms per try, outside any timed region.
         Returns the report also stored in ``self.placement``."""
         params, dev = self.params, self.params.device
         tries = getattr(params, "placement_tries", 0)
@@ -165,7 +165,7 @@ class BlockGrid:
         if min_bytes is None:
             min_bytes = getattr(params, "placement_min_bytes", 256 << 20)
         if spare is None:
-            spare = 8 if keep_state else 4
+            spare = 8
         if self.alt is None or tries <= 1 or nbytes < min_bytes:
             return None
         free, _total = dev.memory_info()

@@ -348,7 +348,7 @@ def test_tune_placement_keeps_the_state(oracle):
         assert (stats.data.placement is not None) == (opts["placement_tries"] > 1)
         if stats.data.placement:
             rep = stats.data.placement
-            assert 2 <= rep["tries"] <= 6 and len(rep["x_plus_y_ms"]) == rep["tries"] and rep["pool"] == 12
+            assert 2 <= rep["tries"] <= 6 and len(rep["x_plus_y_ms"]) == rep["tries"] and rep["pool"] == 16
         assert np.array_equal(oracle.real_view(host["rho"], 96, 64, G), oracle.real_view(ref_fields["rho"], 96, 64, G))
 
 
