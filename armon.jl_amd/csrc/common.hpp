@@ -85,7 +85,7 @@ inline void range_grid(const armon_range& r, int cells_per_thread, dim3& grid, d
 {
     block = dim3(kBlock, 1, 1);
     int64_t per_block = (int64_t)kBlock * cells_per_thread;
-    int64_t gx = (r.row_len + per_block - 1) / per_block;
+    int64_t gx = (r.row_len + 15 + per_block - 1) / per_block;      // + the sector-alignment shift of the row walks
     int64_t gy = r.col_len < 65535 ? r.col_len : 65535;
     grid = dim3((unsigned)gx, (unsigned)gy, 1);
 }

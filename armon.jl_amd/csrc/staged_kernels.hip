@@ -22,9 +22,18 @@ __device__ __forceinline__ int64_t row_base(const armon_range& r, int64_t j)
 // stores, so that they do not displace the neighbour rows the stencils DO re-read from L2.
 template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
+// Threads are laid along a row of the range, shifted left so that every wave's row segment starts on a 64-B sector
+// of the array (ranges start g or g-w cells into a row: without the shift each 512-B segment straddles one more sector;
+// the fused sweeps gained 9-11 % from the same alignment). Grids are sized for row_len + 15 threads.
+template <typename T> __device__ __forceinline__ int64_t row_thread(const armon_range& r)
+{
+    constexpr int64_t per_sector = 64 / sizeof(T);
+    return (int64_t)blockIdx.x * blockDim.x + threadIdx.x - ((r.col_start + r.row_start) & (per_sector - 1));
+}
+
 #define ARMON_FOR_RANGE(r, i)                                                         \
-    const int64_t k_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;                 \
-    if (k_ < (r).row_len)                                                              \
+    const int64_t k_ = row_thread<T>(r);                                               \
+    if (k_ >= 0 && k_ < (r).row_len)                                                   \
         for (int64_t j_ = blockIdx.y, i = row_base((r), j_) + k_; j_ < (r).col_len;    \
              j_ += gridDim.y, i = row_base((r), j_) + k_)
 
@@ -39,9 +48,9 @@ k_perfect_gas_EOS(armon_range r, T gamma, const T* __restrict__ rho,
     ARMON_FOR_RANGE(r, i) {
         T pi, ci;
         phys::perfect_gas(gamma, rho[i], E[i], u[i], v[i], pi, ci);
-        p[i] = pi;
-        c[i] = ci;
-        g[i] = (T(1.) + gamma) / 2;
+        st_stream(p + i, pi);
+        st_stream(c + i, ci);
+        st_stream(g + i, (T(1.) + gamma) / 2);
     }
 }
 
@@ -55,9 +64,9 @@ k_bizarrium_EOS(armon_range r, const T* __restrict__ rho, const T* __restrict__ 
     ARMON_FOR_RANGE(r, i) {
         T pi, ci, gi;
         phys::bizarrium<true>(rho[i], E[i], u[i], v[i], pi, ci, gi);
-        p[i] = pi;
-        c[i] = ci;
-        g[i] = gi;
+        st_stream(p + i, pi);
+        st_stream(c + i, ci);
+        st_stream(g + i, gi);
     }
 }
 
@@ -71,8 +80,8 @@ k_acoustic(armon_range r, int64_t s, T* __restrict__ us, T* __restrict__ ps,
     ARMON_FOR_RANGE(r, i) {
         T a, b;
         phys::godunov(rho[i], rho[i - s], c[i], c[i - s], u[i], u[i - s], p[i], p[i - s], a, b);
-        us[i] = a;
-        ps[i] = b;
+        st_stream(us + i, a);
+        st_stream(ps + i, b);
     }
 }
 
@@ -150,8 +159,8 @@ __global__ void __launch_bounds__(kBlock)
 k_acoustic_GAD_y(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us, T* __restrict__ ps, const T* __restrict__ rho,
                  const T* __restrict__ u, const T* __restrict__ p, const T* __restrict__ c)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= r.row_len) return;
+    const int64_t k = row_thread<T>(r);
+    if (k < 0 || k >= r.row_len) return;
     const int64_t j0 = (int64_t)blockIdx.y * kGadRows;
     const int64_t j1 = (j0 + kGadRows < r.col_len) ? j0 + kGadRows : r.col_len;
     int64_t i = row_base(r, j0) + k;
@@ -334,8 +343,8 @@ k_advection_second_order_y(armon_range r, int64_t s, T dx, T dt, const T* __rest
                            const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ E,
                            T* __restrict__ a_rho, T* __restrict__ a_urho, T* __restrict__ a_vrho, T* __restrict__ a_Erho)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= r.row_len) return;
+    const int64_t k = row_thread<T>(r);
+    if (k < 0 || k >= r.row_len) return;
     const int64_t j0 = (int64_t)blockIdx.y * kAdvRows;
     const int64_t j1 = (j0 + kAdvRows < r.col_len) ? j0 + kAdvRows : r.col_len;
     int64_t i = row_base(r, j0) + k;
