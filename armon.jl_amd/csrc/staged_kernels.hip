@@ -118,7 +118,7 @@ k_acoustic_GAD(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us,
 //    window of the last two cells and three solutions. kGadRows fluxes per kGadRows + 2 solves.
 // No cell outside the reference's own stencil [i - 2s, i + s] of the range is read.
 constexpr int kGadValid = 62;
-constexpr int kGadRows = 32;
+constexpr int kGadRows = 64;
 
 template <int LIM, typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -276,7 +276,7 @@ k_advection_second_order(armon_range r, int64_t s, T dx, T dt,
 //  * sweep along y: lane ↔ column, kAdvRows rows per thread with rolling windows — 5 loads per row.
 // No cell outside the reference's own stencil (uˢ @ is-2s..is+2s; ρ,u,v,E @ is-2s..is+s) is read.
 constexpr int kAdvValid = 60;
-constexpr int kAdvRows = 32;
+constexpr int kAdvRows = 64;
 
 template <typename T> struct adv_cell { T rho, qu, qv, qE; };
 

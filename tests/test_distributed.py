@@ -43,6 +43,42 @@ def test_halo_exchange_more_ranks(tmp_path, P, N):
         assert lines[0] == "OK", lines
 
 
+@pytest.mark.parametrize("P,N", [((2, 2), (107, 113)), ((1, 3), (37, 241)), ((4, 2), (96, 48)), ((5, 1), (20, 20))])
+def test_halo_exchange_reference_domains_and_the_8_gpu_layout(tmp_path, P, N):
+    """The reference's uneven MPI test domains (ref test/mpi.jl:551-561: 107×113, 37×241, 20×20) and the 4×2 layout of
+    BASELINE config 5, with the partition rule checked on every rank (N ÷ P, remainder on the last rank of the axis)."""
+    world = P[0] * P[1]
+    spawn(dist_workers.halo_index_worker, world, P, N, str(tmp_path))
+    for r in range(world):
+        lines = open(tmp_path / f"rank{r}.txt").read().splitlines()
+        assert lines[0] == "OK", lines
+        size = eval(lines[1].split(") (")[0] + ")")
+        cx, cy = r // P[1], r % P[1]
+        assert size[0] == N[0] // P[0] + (N[0] % P[0] if cx == P[0] - 1 else 0)
+        assert size[1] == N[1] // P[1] + (N[1] % P[1] if cy == P[1] - 1 else 0)
+
+
+def test_native_halo_ranges_match_the_reference_domains():
+    """armon_hip_halo_ranges (what the library's own halo exchange packs and unpacks) against border_domain /
+    ghost_domain of ref src/blocking/blocking.jl:141-187 as mirrored in blocking.py — no GPU needed."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.blocking import BlockSize, Side
+    L = armon_amd.lib()
+    for nx, ny, g in [(24, 16, 4), (37, 41, 4), (5, 7, 2), (64, 64, 5), (107, 113, 4), (1, 9, 1)]:
+        bs = BlockSize((nx + 2 * g, ny + 2 * g), g)
+        for tag, side in enumerate((Side.Left, Side.Right, Side.Bottom, Side.Top)):
+            b, gh, face = _lib.Range(), _lib.Range(), C.c_int64()
+            assert L.armon_hip_halo_ranges(nx, ny, g, tag, C.byref(b), C.byref(gh), C.byref(face)) == 0
+            for got, ref in ((b, bs.border_domain(side, single_strip=False).to_c()),
+                             (gh, bs.ghost_domain(side, single_strip=False).to_c())):
+                assert ((got.col_start, got.col_step, got.col_len, got.row_start, got.row_len)
+                        == (ref.col_start, ref.col_step, ref.col_len, ref.row_start, ref.row_len)), (nx, ny, g, side)
+            assert face.value == bs.real_face_size(side)
+    assert L.armon_hip_halo_ranges(0, 4, 4, 0, None, None, None) != 0            # empty tile is an error, not a crash
+
+
 def test_split_too_small_for_ghosts_is_rejected():
     """ref src/parameters.jl:684-690"""
     import armon_amd

@@ -368,3 +368,45 @@ def test_tuning_knobs_do_not_change_results(monkeypatch, knobs, exact):
     assert stats.cycles == ref_stats.cycles and stats.last_dt == ref_stats.last_dt
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(stats.data.real_view(host[k]), ref_stats.data.real_view(ref[k])), k
+
+
+@pytest.mark.parametrize("test,N", [("Sod_circ", (300, 200)), ("Sod_circ", (57, 61)), ("Sedov", (123, 77)), ("Sod", (8, 500)),
+                                    ("Sod_y", (500, 9))])
+def test_whole_cycle_kernel_equals_the_two_sweeps(test, N):
+    """armon_hip_cycle_xy (X sweep + Y sweep in ONE pass over memory, the intermediate state in registers) gives the
+    bits of armon_hip_sweep(X) followed by armon_hip_sweep(Y): state, fused dt reduction and the materialised p."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.blocking import Axis
+    from armon_amd.solver import STATE_VARS, BlockGrid, init_test, local_time_step, sweep_desc, update_EOS
+    L = _lib.lib()
+    params = armon_amd.ArmonParameters(test=test, N=N, silent=5, maxcycle=10)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    dev = params.device
+    dx, dy = params.cell_size(0), params.cell_size(1)
+    update_EOS(params, grid)
+    dt = params.cfl * local_time_step(params, grid)               # the reference's first time step
+    for emit_p in (False, True):
+        d_x = sweep_desc(params, grid, Axis.X, dt, dx)
+        d_y = sweep_desc(params, grid, Axis.Y, dt, dy, emit_dt=True, emit_p=emit_p)
+        _lib.check(L.armon_hip_cycle_xy(dev.ctx, C.byref(d_x), C.byref(d_y)))           # data -> alt
+        got = {f: grid.alt[f].to_host() for f in STATE_VARS}
+        got_dt = grid.dt_scalar.to_host()[0]
+        got_p = grid.data["p"].to_host() if emit_p else None
+        tmp = {f: dev.empty(grid.data[f].n, grid.data[f].dtype) for f in STATE_VARS}
+        _lib.check(params.fn("sweep")(dev.ctx, C.byref(d_x)))                           # data -> alt
+        d_y.rho_in, d_y.u_in, d_y.v_in, d_y.E_in = (grid.alt[f].ptr for f in STATE_VARS)
+        d_y.rho_out, d_y.u_out, d_y.v_out, d_y.E_out = (tmp[f].ptr for f in STATE_VARS)
+        _lib.check(params.fn("sweep")(dev.ctx, C.byref(d_y)))                           # alt -> tmp
+        assert got_dt == grid.dt_scalar.to_host()[0]
+        for f in STATE_VARS:
+            assert np.array_equal(grid.real_view(got[f]), grid.real_view(tmp[f].to_host())), f
+        if emit_p:
+            assert np.array_equal(grid.real_view(got_p), grid.real_view(grid.data["p"].to_host()))
+    # unsupported combinations are refused, not approximated
+    d_x = sweep_desc(params, grid, Axis.X, dt, dx)
+    d_y = sweep_desc(params, grid, Axis.Y, dt, dy)
+    d_x.exact = d_y.exact = 1
+    assert L.armon_hip_cycle_xy(dev.ctx, C.byref(d_x), C.byref(d_y)) != 0
