@@ -114,6 +114,11 @@ def cpu_baseline(test, scheme, target_seconds=12.0):
 
 
 def main():
+    # The contract is ONE JSON line on stdout. RCCL and gloo print banners on fd 1 while they initialise: send
+    # everything written to fd 1 during the run to stderr and keep the real stdout for that line alone.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -380,7 +385,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "Mcells/s per sweep", "cores": 0,
                                    "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
