@@ -187,30 +187,53 @@ class BlockGrid:
             return None
         d_x = sweep_desc(params, self, Axis.X, dt, dx)
         d_y = sweep_desc(params, self, Axis.Y, dt, params.cell_size(1), emit_dt=True)     # as in a cycle
-        ptrs = (C.c_void_p * len(pool))(*[v.ptr for v in pool])
-        picks, times, done = (C.c_int * 8)(), (C.c_double * tries)(), C.c_int(tries)
-        try:
-            if keep_state:
-                check(params.fn("tune_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes, tries,
-                                                  C.byref(picks), times))
-            else:
-                check(params.fn("choose_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes, tries,
-                                                    0.01, C.byref(picks), times, C.byref(done)))
-        except _lib.SolverException:          # e.g. no room for the 4 transient vectors: nothing was moved
-            for v in pool[8:]:
-                v.free()
-            return None
-        picks, times = list(picks), list(times)[:done.value]
+        # A search can come back empty-handed: in about one process in four none of the draws of a 16-vector pool
+        # reaches the fast level (profiles/r02_placement_pool_sizes.txt). The fast level is recognisable on its own —
+        # an X + Y pair then streams its 16 vectors' worth of bytes at >= 0.93 of the 6.29 TB/s this part sustains —
+        # so when the best draw stays below that, a fresh batch of spares is allocated NEXT TO the losers (freeing them
+        # first would hand back the same memory) and the search is repeated with the best assignment so far as its
+        # first draw, at most `placement_rounds` times. (Arithmetic-bound sweeps — exact flavour, Bizarrium — may never
+        # reach the mark: they just use their rounds.)
+        rounds = max(1, int(getattr(params, "placement_rounds", 3))) if not keep_state else 1
+        fast_ms = 2 * 8 * nbytes / (0.93 * 6.29e12) * 1e3
+        losers, all_times, report_rounds = [], [], 0
+        while True:
+            report_rounds += 1
+            ptrs = (C.c_void_p * len(pool))(*[v.ptr for v in pool])
+            picks, times, done = (C.c_int * 8)(), (C.c_double * tries)(), C.c_int(tries)
+            try:
+                if keep_state:
+                    check(params.fn("tune_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes, tries,
+                                                      C.byref(picks), times))
+                else:
+                    check(params.fn("choose_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes,
+                                                        tries, 0.01, C.byref(picks), times, C.byref(done)))
+            except _lib.SolverException:          # e.g. no room for the 4 transient vectors: nothing was moved
+                for v in pool[8:] + losers:
+                    v.free()
+                return None
+            picks, times = list(picks), list(times)[:done.value]
+            all_times.append([round(t, 3) for t in times])
+            best = [pool[k] for k in picks]
+            losers += [v for i, v in enumerate(pool) if i not in set(picks)]
+            if min(times) <= fast_ms or report_rounds >= rounds:
+                break
+            free, _total = dev.memory_info()
+            if free < (spare + 2) * nbytes:
+                break
+            try:
+                pool = best + [dev.empty(n, dt_) for _ in range(spare)]
+            except _lib.SolverException:
+                break
         for k, f in enumerate(STATE_VARS):
-            self.data[f], self.alt[f] = pool[picks[k]], pool[picks[4 + k]]
-        keep = set(picks)
-        for i, v in enumerate(pool):
-            if i not in keep:
-                v.free()
-        k = times.index(min(times))
-        self.placement = {"tries": len(times), "max_tries": tries, "pool": len(pool),
-                          "x_plus_y_ms": [round(t, 3) for t in times], "chosen": k, "chosen_ms": round(times[k], 3),
-                          "transient_GB": round((spare + (4 if keep_state else 0)) * nbytes / 1e9, 2)}
+            self.data[f], self.alt[f] = best[k], best[4 + k]
+        for v in losers:
+            v.free()
+        flat = [t for r in all_times for t in r]
+        self.placement = {"tries": len(flat), "max_tries": tries, "pool": 8 + spare, "rounds": report_rounds,
+                          "x_plus_y_ms": all_times[0] if report_rounds == 1 else all_times,
+                          "chosen_ms": round(min(all_times[-1]), 3), "fast_level_ms": round(fast_ms, 3),
+                          "transient_GB": round((report_rounds * spare + (4 if keep_state else 0)) * nbytes / 1e9, 2)}
         return self.placement
 
     def device_to_host(self, names=MAIN_VARS):

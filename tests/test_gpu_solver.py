@@ -342,13 +342,16 @@ def test_tune_placement_keeps_the_state(oracle):
     # and whole runs with the placement chosen before init_test (armon_hip_choose_placement, what armon() does at
     # full size), forced here on a small block, or with no tuning at all, give the oracle's result
     ref, ref_fields = oracle.solve(test="Sod_circ", N=(96, 64), maxcycle=6)
-    for opts in (dict(placement_tries=6, placement_min_bytes=0), dict(placement_tries=1)):
+    for opts in (dict(placement_tries=6, placement_min_bytes=0, placement_rounds=1),
+                 dict(placement_tries=4, placement_min_bytes=0, placement_rounds=2), dict(placement_tries=1)):
         _p, stats, host = run("Sod_circ", N=(96, 64), maxcycle=6, **opts)
         assert stats.cycles == ref.cycles
         assert (stats.data.placement is not None) == (opts["placement_tries"] > 1)
         if stats.data.placement:
             rep = stats.data.placement
-            assert 2 <= rep["tries"] <= 6 and len(rep["x_plus_y_ms"]) == rep["tries"] and rep["pool"] == 16
+            assert rep["pool"] == 16 and rep["rounds"] == opts["placement_rounds"]   # a tiny block never reaches the fast mark
+            assert rep["tries"] == opts["placement_tries"] * rep["rounds"]
+            assert len(rep["x_plus_y_ms"]) == (rep["tries"] if rep["rounds"] == 1 else rep["rounds"])
         assert np.array_equal(oracle.real_view(host["rho"], 96, 64, G), oracle.real_view(ref_fields["rho"], 96, 64, G))
 
 
