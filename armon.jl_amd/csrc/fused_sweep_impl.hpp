@@ -772,6 +772,172 @@ k_cycle_xy(sweep_args a, real dt_y, real dx_y)
     if (TRACK) cfl_block_store<4>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
 
+// ---- whole cycle, producer / consumer waves (x_kernel = 4; measured alternative) -------------------------------------
+// k_cycle_xy above needs the registers of BOTH stages in every wave (≈340: one wave per SIMD, VALU-bound). Here the
+// stages live in different waves of a 3-wave workgroup and meet in LDS:
+//   wave 0 (producer)  : X stage of one row of a 128-cell strip (2 cells per lane, DPP shifts, the X sweep's own code),
+//                        120 X-swept cells written to a two-row LDS ring (4 KB per row);
+//   waves 1, 2 (consumers): each marches 64 / 56 of those columns down y with the Y sweep's register pipeline, reading
+//                        the row the producer finished in the previous iteration.
+// One workgroup barrier per row hands a row over (iteration t: the producer works on row t while the consumers work on
+// row t-1; the slot written in iteration t+1 is the one read in iteration t-1). Bit-identical to the two sweeps, and
+// the VALU work per cell is theirs while the HBM traffic halves — but a kernel has ONE register allocation: hipcc
+// (ROCm 7.2) does not overlay the two roles' registers (143 alone + 166 alone -> 256 + 136 B of scratch inside the row
+// loops, whether the roles are branches of one loop, separate loops, scoped blocks or — unconstrained — non-inlined
+// functions at 248 / 256), and with the spills it runs at 11.5 ms per cycle against 5.7 ms for the two launches.
+// Kept selectable for that record; it needs either a register budget per role (hand-written assembly) or a march
+// whose rings live in LDS.
+constexpr int kPcValid = 120;
+
+// geometry of one workgroup of k_cycle_pc, shared by its two roles
+struct pc_geom { int64_t w0; int o0, o1, jb, T; };
+constexpr int kPcWidth = 128, kPcHalo = 4;
+typedef real pc_ring_t[2][4][kPcWidth];
+
+// The roles are separate NON-INLINED functions: inlined into one kernel body, the register allocator adds the two
+// roles' registers up (143 + 166 -> 256 VGPRs + scratch); as calls, the kernel needs the larger of the two.
+template <int SCHEME, int LIM, int PROJ, int EOS>
+__device__ __forceinline__ void pc_producer(const sweep_args& a, const pc_geom& gm, pc_ring_t& ring)
+{
+    using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, false, 2, real>;
+    using St = fused::Strip<2, real>;
+    constexpr int HALO = kPcHalo, WIDTH = kPcWidth;
+    const int lane = threadIdx.x & 63;
+    const int64_t nx = a.nx, w0 = gm.w0;
+    const int ny = (int)a.ny, g = a.g, jb = gm.jb, T = gm.T;
+        // ---- producer: X stage of row jb + t into ring slot t & 1
+        SW sw{a.dt, a.dx, a.gamma};
+        St buf[2][4];
+        const int64_t cb = w0 - HALO;                                    // first cell of the strip
+        const int64_t j0 = cb + 2 * (int64_t)lane;                       // this lane's first cell
+        const bool interior = cb >= 0 && cb + WIDTH <= nx;               // no ghost column, no clamping
+        const bool vec_ok = (a.row_len % 2 == 0) && ((cb + g) % 2 == 0);
+        auto load_row = [&](auto slot, int t) {
+            constexpr int B = decltype(slot)::value;
+            const int j = jb + t;
+            const bool m_lo = j < 0 && a.bc_low_t, m_hi = j >= ny && a.bc_high_t;    // y boundary: mirror rows
+            const int src_row = m_lo ? -1 - j : (m_hi ? 2 * ny - 1 - j : j);
+            const real fu = m_lo ? a.tu_low : (m_hi ? a.tu_high : real(1));
+            const real fv = m_lo ? a.tv_low : (m_hi ? a.tv_high : real(1));
+            const int64_t row_off = ((int64_t)src_row + g) * a.row_len + g;
+            const real* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
+            St& rho = buf[B][0];
+            St& u = buf[B][1];
+            St& v = buf[B][2];
+            St& E = buf[B][3];
+            if (interior && vec_ok) {
+                const vec2 r = ld2(in[0] + j0), uu = ld2(in[1] + j0), vv = ld2(in[2] + j0), e = ld2(in[3] + j0);
+                rho.v[0] = r.x; rho.v[1] = r.y;
+                u.v[0] = uu.x * fu; u.v[1] = uu.y * fu;
+                v.v[0] = vv.x * fv; v.v[1] = vv.y * fv;
+                E.v[0] = e.x; E.v[1] = e.y;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    int64_t jc = j0 + k;
+                    jc = jc < -(int64_t)g ? -(int64_t)g : (jc > nx + g - 1 ? nx + g - 1 : jc);
+                    real fa, ft;
+                    const int64_t src = bc_source(a, nx, jc, fa, ft);    // x boundary: mirror columns
+                    rho.v[k] = in[0][src];
+                    u.v[k] = in[1][src] * fa * fu;
+                    v.v[k] = in[2][src] * ft * fv;
+                    E.v[k] = in[3][src];
+                }
+            }
+        };
+        load_row(std::integral_constant<int, 0>{}, 0);
+        for (int t0 = 0; t0 <= T; t0 += 2)
+            static_for(std::make_integer_sequence<int, 2>{}, [&](auto ph) {
+                constexpr int B = decltype(ph)::value;
+                const int t = t0 + B;
+                if (t <= T) {
+                    if (t < T) {
+                        if (t + 1 < T) load_row(std::integral_constant<int, 1 - B>{}, t + 1);   // next row in flight during this one
+                        St o_rho, o_u, o_v, o_E, p, cs;
+                        sw.run(buf[B][0], buf[B][1], buf[B][2], buf[B][3], o_rho, o_u, o_v, o_E, p, cs);
+                        vreal2* dst = reinterpret_cast<vreal2*>(&ring[B][0][0]);
+                        dst[0 * (WIDTH / 2) + lane] = vreal2{o_rho.v[0], o_rho.v[1]};
+                        dst[1 * (WIDTH / 2) + lane] = vreal2{o_u.v[0], o_u.v[1]};
+                        dst[2 * (WIDTH / 2) + lane] = vreal2{o_v.v[0], o_v.v[1]};
+                        dst[3 * (WIDTH / 2) + lane] = vreal2{o_E.v[0], o_E.v[1]};
+                    }
+                    __syncthreads();
+                }
+            });
+}
+
+template <int SCHEME, int LIM, int PROJ, int EOS, bool TRACK>
+__device__ __forceinline__ void pc_consumer(const sweep_args& a, const pc_geom& gm, pc_ring_t& ring, real dt_y, real dx_y,
+                                                      int role, cfl_track& cfl)
+{
+    using PIPE = fused::PipeFast<SCHEME, LIM, PROJ, EOS, real>;
+    constexpr int LAG = PIPE::LAG, HALO = kPcHalo;
+    const int lane = threadIdx.x & 63;
+    const int64_t nx = a.nx, w0 = gm.w0;
+    const int g = a.g, jb = gm.jb, T = gm.T, o0 = gm.o0, o1 = gm.o1;
+    // keep the march's initial state from being hoisted above the role branch (it would stay live through the producer)
+    asm volatile("" : "+v"(dt_y), "+v"(dx_y));
+        // ---- consumers: wave 1 marches produced cells 0..63, wave 2 cells 64..119; row t - 1 from ring slot (t - 1) & 1
+        PIPE pipe(dt_y, dx_y, a.gamma);
+        const int pc = (role == 2 ? 64 : 0) + lane;                      // produced cell of this lane
+        const int ci = HALO + (pc < kPcValid ? pc : kPcValid - 1);       // its place in the strip
+        const int64_t xr = w0 + pc;
+        const bool active = pc < kPcValid && xr >= 0 && xr < nx;
+        const unsigned colw = (unsigned)((active ? xr : 0) + g) * (unsigned)sizeof(real);
+        const unsigned pitchb = (unsigned)a.row_len * (unsigned)sizeof(real);
+        const int64_t out_base = (int64_t)(o0 + g) * a.row_len;
+        const rsrc_t w_rho = make_rsrc(a.rho_out + out_base), w_u = make_rsrc(a.ua_out + out_base);
+        const rsrc_t w_v = make_rsrc(a.ut_out + out_base), w_E = make_rsrc(a.E_out + out_base);
+        for (int t0 = 0; t0 <= T; t0 += 8)
+            static_for(std::make_integer_sequence<int, 8>{}, [&](auto ph) {
+                constexpr int PH = decltype(ph)::value, PH8 = (PH + 7) & 7, B = PH8 & 1;     // phase and ring slot of row t - 1
+                const int t = t0 + PH;
+                if (t <= T) {
+                    if (t >= 1) {
+                        const real rho = ring[B][0][ci], u = ring[B][1][ci], v = ring[B][2][ci], E = ring[B][3][ci];
+                        real pj, cj, c_lag;
+                        const fused::Out4<real> out = pipe.template push<true, PH8>(rho, v, u, E, pj, cj, c_lag);   // Y march: ua = v, ut = u
+                        const int j = jb + t - 1, o = j - LAG;
+                        if ((a.emit & 1) && j >= o0 && j < o1 && active)
+                            buf_store(make_rsrc(a.p_out + out_base), colw, (unsigned)(j - o0) * pitchb, pj);
+                        if (o >= o0 && o < o1 && active) {
+                            const unsigned so_off = (unsigned)(o - o0) * pitchb;
+                            buf_store(w_rho, colw, so_off, out.rho);
+                            buf_store(w_u, colw, so_off, out.ut);
+                            buf_store(w_v, colw, so_off, out.ua);
+                            buf_store(w_E, colw, so_off, out.E);
+                            if (TRACK) cfl.add(out.ut, out.ua, c_lag);
+                        }
+                    }
+                    __syncthreads();
+                }
+            });
+}
+
+template <int SCHEME, int LIM, int PROJ, int EOS, bool TRACK>
+#ifndef ARMON_PC_WAVES
+#define ARMON_PC_WAVES 2
+#endif
+__global__ void __launch_bounds__(192, ARMON_PC_WAVES)
+k_cycle_pc(sweep_args a, real dt_y, real dx_y)
+{
+    constexpr int LAG = fused::PipeTraits<SCHEME, LIM, PROJ, EOS>::LAG;
+    static_assert(LAG <= kPcHalo, "strip halo");
+    __shared__ __attribute__((aligned(16))) pc_ring_t ring;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and the compiler is told so
+    pc_geom gm;
+    gm.w0 = a.x_first + (int64_t)blockIdx.x * kPcValid;      // first column this workgroup produces (may be < 0)
+    gm.o0 = (int)a.o_lo + (int)blockIdx.y * a.seg;
+    gm.o1 = (gm.o0 + a.seg < (int)a.o_hi) ? gm.o0 + a.seg : (int)a.o_hi;
+    gm.jb = gm.o0 - LAG;
+    gm.T = gm.o1 + LAG - gm.jb;                               // rows to X-sweep
+    cfl_track cfl;
+    // both roles run T + 1 barriers
+    if (role == 0) pc_producer<SCHEME, LIM, PROJ, EOS>(a, gm, ring);
+    else pc_consumer<SCHEME, LIM, PROJ, EOS, TRACK>(a, gm, ring, dt_y, dx_y, role, cfl);
+    if (TRACK) cfl_block_store<3>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
+}
+
 // ---- X sweep, LDS-transposed march (alternative form) -----------------------------------------------------
 constexpr int kXRows = 64;      // one wave: lane ↔ row
 constexpr int kXChunk = 8;
@@ -1287,6 +1453,7 @@ extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const A
                   x->eos == ARMON_EOS_PERFECT_GAS && !x->exact, "whole-cycle kernel: GAD + minmod + euler_2nd, perfect gas, tuned arithmetic only");
     ARMON_REQUIRE(x->nx > 0 && x->ny > 0 && x->nx < (1ll << 30) && x->ny < (1ll << 30), "invalid block %lld x %lld", (long long)x->nx, (long long)x->ny);
     ARMON_REQUIRE(x->out_hi == 0 && !x->p_out && !x->c_out && !x->dt_cfl_out, "partial X sweeps / X outputs are not available in the whole-cycle kernel");
+    ARMON_REQUIRE(x->x_kernel == 0 || x->x_kernel == 4, "unknown form %d of the whole-cycle kernel", x->x_kernel);
     ARMON_REQUIRE(x->rho_in && x->u_in && x->v_in && x->E_in && y->rho_out && y->u_out && y->v_out && y->E_out, "NULL state array");
     ARMON_REQUIRE(x->rho_in != y->rho_out && x->u_in != y->u_out && x->v_in != y->v_out && x->E_in != y->E_out, "in and out arrays must not alias");
     constexpr int lag = 4;
@@ -1320,7 +1487,6 @@ extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const A
     a.p_out = y->p_out;
     a.c_out = nullptr;
     a.x_kernel = 0;
-    a.x_first = 0;
     a.xshift = 0;
     a.xcd_remap = 0;
     a.o_lo = 0;
@@ -1330,9 +1496,12 @@ extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const A
         a.o_lo = y->out_lo;
         a.o_hi = y->out_hi;
     }
-    const int64_t waves_x = (x->nx + 55) / 56, blocks_x = (waves_x + 3) / 4;
-    {   // run length: same model as the Y march, with this kernel's residency (ARMON_C_WAVES waves per SIMD)
-        const double slots = (double)ctx->n_cu * ARMON_C_WAVES;
+    const bool pc_form = x->x_kernel == 4;                   // 0: one wave does both stages (k_cycle_xy); 4: producer / consumer waves
+    a.x_first = pc_form ? -(int64_t)(x->nghost % 8) : 0;     // stores start on a 64-B sector of the ghosted row
+    const int64_t waves_x = (x->nx + 55) / 56;
+    const int64_t blocks_x = pc_form ? (x->nx - a.x_first + kPcValid - 1) / kPcValid : (waves_x + 3) / 4;
+    {   // run length: same model as the Y march, with this kernel's residency
+        const double slots = pc_form ? (double)ctx->n_cu * 2 : (double)ctx->n_cu * ARMON_C_WAVES;
         int best = (int)(x->ny < 32 ? x->ny : 32);
         double best_cost = 1e300;
         for (int64_t nruns = 1; nruns <= x->ny; nruns++) {
@@ -1357,7 +1526,12 @@ extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const A
         a.partials = reinterpret_cast<real*>(ctx->partials);
     }
     constexpr int S = ARMON_SCHEME_GAD, L = ARMON_LIMITER_MINMOD, P = ARMON_PROJECTION_EULER_2ND, E = ARMON_EOS_PERFECT_GAS;
-    if (track)
+    if (pc_form) {
+        if (track)
+            hipLaunchKernelGGL((k_cycle_pc<S, L, P, E, true>), grid, dim3(192), 0, ctx->stream, a, (real)y->dt, (real)y->dx);
+        else
+            hipLaunchKernelGGL((k_cycle_pc<S, L, P, E, false>), grid, dim3(192), 0, ctx->stream, a, (real)y->dt, (real)y->dx);
+    } else if (track)
         hipLaunchKernelGGL((k_cycle_xy<S, L, P, E, false, true>), grid, dim3(256), 0, ctx->stream, a, (real)y->dt, (real)y->dx);
     else
         hipLaunchKernelGGL((k_cycle_xy<S, L, P, E, false, false>), grid, dim3(256), 0, ctx->stream, a, (real)y->dt, (real)y->dx);

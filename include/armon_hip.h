@@ -303,7 +303,9 @@ ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
  * boundary; y_desc the Y sweep's, plus p_out (EOS pressure of the state before the Y sweep), dt_cfl_out and an
  * optional row range out_lo/out_hi. Results are the bits of armon_hip_sweep(x_desc) followed by armon_hip_sweep(y_desc).
  * fp64, GAD + minmod + euler_2nd, perfect gas, tuned arithmetic only; a block whose Y sides are remote cannot use it
- * (the rows received from a neighbour would have to be X-swept first). No reference counterpart. */
+ * (the rows received from a neighbour would have to be X-swept first). x_desc->x_kernel selects the form: 0 = one wave
+ * runs both stages, 4 = producer / consumer waves through LDS. Both are measured alternatives (register-bound, slower
+ * than the two launches today: DESIGN.md section 4.2), not what the solver runs. No reference counterpart. */
 ARMON_API int armon_hip_cycle_xy(armon_ctx*, const armon_sweep_desc* x_desc, const armon_sweep_desc* y_desc);
 
 /* Placement of the 8 vectors a fused sweep streams (4 read + 4 written). On MI355X the same sweeps run 10-20 %

@@ -391,10 +391,12 @@ def test_whole_cycle_kernel_equals_the_two_sweeps(test, N):
     dx, dy = params.cell_size(0), params.cell_size(1)
     update_EOS(params, grid)
     dt = params.cfl * local_time_step(params, grid)               # the reference's first time step
-    for emit_p in (False, True):
+    for emit_p, form in ((False, 0), (True, 0), (False, 4), (True, 4)):       # form 4: producer / consumer waves
         d_x = sweep_desc(params, grid, Axis.X, dt, dx)
         d_y = sweep_desc(params, grid, Axis.Y, dt, dy, emit_dt=True, emit_p=emit_p)
+        d_x.x_kernel = form
         _lib.check(L.armon_hip_cycle_xy(dev.ctx, C.byref(d_x), C.byref(d_y)))           # data -> alt
+        d_x.x_kernel = 0
         got = {f: grid.alt[f].to_host() for f in STATE_VARS}
         got_dt = grid.dt_scalar.to_host()[0]
         got_p = grid.data["p"].to_host() if emit_p else None
