@@ -286,10 +286,62 @@ def _range(params, corners):
 
 
 def init_test(params, grid, tune=True):
-    """ref src/kernels.jl:176-207 (+ the measured choice of the HBM placement of the state vectors, made BEFORE they
-    are written; ``tune=False`` to skip it, e.g. when re-initialising a grid that has been placed already)"""
+    """ref src/kernels.jl:176-207 (+ the measured choice of the HBM placement of the vectors, made BEFORE they are
+    written; ``tune=False`` to skip it, e.g. when re-initialising a grid that has been placed already)"""
     if tune and grid.placement is None:
-        grid.tune_placement(keep_state=False)
+        if params.use_fused_sweep:
+            grid.tune_placement(keep_state=False)
+        else:
+            tune_staged_placement(params, grid)
+    _init_test_kernel(params, grid)
+
+
+def tune_staged_placement(params, grid, min_bytes=None):
+    """The staged path's counterpart of ``BlockGrid.tune_placement``: the 16 ``BlockData`` vectors have the same size,
+    so ANY assignment of the 16 allocations to the 16 fields is a valid layout, and which one is taken moves the staged
+    kernels by 5-20 % (advection_second_order 3.25 ... 4.0 ms at 16384², tools/staged_placement_probe.py). A few random
+    assignments are timed with one staged cycle (X then Y: EOS, boundary conditions, fluxes, cell update, advection,
+    projection) on the initial condition, the fastest is kept. No extra memory; ≈40 ms per try, before any timed region."""
+    import random
+    tries = min(8, getattr(params, "placement_tries", 0))
+    nbytes = grid.data["rho"].nbytes
+    if min_bytes is None:
+        min_bytes = getattr(params, "placement_min_bytes", 256 << 20)
+    if tries <= 1 or nbytes < min_bytes or params.use_MPI:
+        return None
+    dev = params.device
+    vectors = [grid.data[f] for f in FIELDS]
+    rng = random.Random(0x5EED)
+    dx = params.cell_size(0)
+    dt = params.T(0.2) * dx
+    times, perms = [], []
+    callbacks, params.kernel_callbacks = params.kernel_callbacks, []
+    for t in range(tries):
+        perm = list(range(len(FIELDS))) if t == 0 else rng.sample(range(len(FIELDS)), len(FIELDS))
+        for f, k in zip(FIELDS, perm):
+            grid.data[f] = vectors[k]
+        _init_test_kernel(params, grid)
+        update_EOS(params, grid)
+        dev.event_record(1002)
+        for axis in (Axis.X, Axis.Y):
+            update_EOS(params, grid, axis)
+            block_ghost_exchange(params, grid, axis)
+            numerical_fluxes(params, grid, axis, dt, params.cell_size(int(axis) - 1))
+            cell_update(params, grid, axis, dt, params.cell_size(int(axis) - 1))
+            projection_remap(params, grid, axis, dt, params.cell_size(int(axis) - 1))
+        dev.event_record(1003)
+        times.append(dev.event_elapsed_ms(1002, 1003))
+        perms.append(perm)
+    params.kernel_callbacks = callbacks
+    k = times.index(min(times))
+    for f, i in zip(FIELDS, perms[k]):
+        grid.data[f] = vectors[i]
+    grid.placement = {"staged": True, "tries": tries, "cycle_ms": [round(t, 3) for t in times], "chosen": k,
+                      "chosen_ms": round(times[k], 3)}
+    return grid.placement
+
+
+def _init_test_kernel(params, grid):
     bs = params.block_size
     full = params.steps_ranges[Axis.X].full_domain
     gpos = (C.c_int64 * 2)(params.N_origin[0] - 1, params.N_origin[1] - 1)
