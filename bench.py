@@ -388,6 +388,9 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        for comm in {id(c): c for c in (grid.comm, locals().get("native_comm")) if c is not None}.values():
+            if hasattr(comm, "close"):
+                comm.close()                   # the library's RCCL communicators, before the launcher's
         dist.destroy_process_group()
 
 
