@@ -299,11 +299,11 @@ def init_test(params, grid, tune=True):
 def tune_staged_placement(params, grid, min_bytes=None):
     """The staged path's counterpart of ``BlockGrid.tune_placement``: the 16 ``BlockData`` vectors have the same size,
     so ANY assignment of the 16 allocations to the 16 fields is a valid layout, and which one is taken moves the staged
-    kernels by 5-20 % (advection_second_order 3.25 ... 4.0 ms at 16384², tools/staged_placement_probe.py). A few random
-    assignments are timed with one staged cycle (X then Y: EOS, boundary conditions, fluxes, cell update, advection,
-    projection) on the initial condition, the fastest is kept. No extra memory; ≈40 ms per try, before any timed region."""
+    kernels by 5-20 % (advection_second_order 3.25 ... 4.0 ms at 16384², tools/staged_placement_probe.py). Up to 12 random
+    assignments — of 16 among the 16 vectors and 8 spares that are freed afterwards — are timed with one staged cycle (X then Y: EOS, boundary conditions, fluxes, cell update, advection,
+    projection) on the initial condition, the fastest is kept. ≈40 ms per try, before any timed region."""
     import random
-    tries = min(8, getattr(params, "placement_tries", 0))
+    tries = getattr(params, "placement_tries", 0)
     nbytes = grid.data["rho"].nbytes
     if min_bytes is None:
         min_bytes = getattr(params, "placement_min_bytes", 256 << 20)
@@ -311,13 +311,20 @@ def tune_staged_placement(params, grid, min_bytes=None):
         return None
     dev = params.device
     vectors = [grid.data[f] for f in FIELDS]
+    free, _total = dev.memory_info()
+    try:        # 8 spare vectors widen the choice (freed afterwards): 16 of 24 allocations
+        n_spare = int(min(8, (free * 0.5) // max(nbytes, 1)))
+        vectors += [dev.empty(vectors[0].n, vectors[0].dtype) for _ in range(max(n_spare, 0))]
+    except _lib.SolverException:
+        pass
+    tries = min(12, getattr(params, "placement_tries", 0))
     rng = random.Random(0x5EED)
     dx = params.cell_size(0)
     dt = params.T(0.2) * dx
     times, perms = [], []
     callbacks, params.kernel_callbacks = params.kernel_callbacks, []
     for t in range(tries):
-        perm = list(range(len(FIELDS))) if t == 0 else rng.sample(range(len(FIELDS)), len(FIELDS))
+        perm = list(range(len(FIELDS))) if t == 0 else rng.sample(range(len(vectors)), len(FIELDS))
         for f, k in zip(FIELDS, perm):
             grid.data[f] = vectors[k]
         _init_test_kernel(params, grid)
@@ -336,7 +343,10 @@ def tune_staged_placement(params, grid, min_bytes=None):
     k = times.index(min(times))
     for f, i in zip(FIELDS, perms[k]):
         grid.data[f] = vectors[i]
-    grid.placement = {"staged": True, "tries": tries, "cycle_ms": [round(t, 3) for t in times], "chosen": k,
+    for i, v in enumerate(vectors):
+        if i not in perms[k]:
+            v.free()
+    grid.placement = {"staged": True, "tries": tries, "pool": len(vectors), "cycle_ms": [round(t, 3) for t in times], "chosen": k,
                       "chosen_ms": round(times[k], 3)}
     return grid.placement
 

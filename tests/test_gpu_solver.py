@@ -356,7 +356,7 @@ def test_tune_placement_keeps_the_state(oracle):
     # the staged path's counterpart: which allocation backs which of the 16 fields is chosen by timing staged cycles
     _p, stats, host = run("Sod_circ", N=(96, 64), maxcycle=6, use_fused_sweep=False, placement_tries=5, placement_min_bytes=0)
     rep = stats.data.placement
-    assert rep and rep["staged"] and rep["tries"] == 5 and len(rep["cycle_ms"]) == 5
+    assert rep and rep["staged"] and rep["tries"] == 5 and len(rep["cycle_ms"]) == 5 and rep["pool"] == 24
     assert stats.cycles == ref.cycles and stats.last_dt == ref.last_dt
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(oracle.real_view(host[k], 96, 64, G), oracle.real_view(ref_fields[k], 96, 64, G)), k
