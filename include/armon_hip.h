@@ -332,43 +332,23 @@ ARMON_API int armon_hip_choose_placement(armon_ctx*, const armon_sweep_desc* x_d
         void* const* pool, int n_pool, size_t bytes, int tries, double tolerance, int picks[8], double* times_ms,
         int* tries_done);
 
+/* fp32 descriptor: field for field the fp64 one (see armon_sweep_desc for the meaning of each), with float arrays;
+ * the scalars stay double and are rounded to float inside. */
 typedef struct {
-    int32_t axis;            /* ARMON_AXIS_X / _Y                                               */
-    int32_t scheme;          /* ARMON_SCHEME_*                                                  */
-    int32_t limiter;         /* ARMON_LIMITER_*  (GAD only)                                     */
-    int32_t projection;      /* ARMON_PROJECTION_*                                              */
-    int32_t eos;             /* ARMON_EOS_*                                                     */
-    int32_t nghost;          /* ghost layers of the arrays (>= scheme·projection stencil)       */
-    int32_t bc_low, bc_high; /* 1: physical boundary on the low/high side of `axis` → mirror BC
-                                applied in-tile; 0: ghosts already hold neighbour data (halo)   */
-    int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to staged  */
-    int32_t x_kernel;        /* X-sweep kernel form, for tests/tuning: 0 default (lanes along x, DPP
-                                shifts, 2 cells per lane), 3 same with 1 cell per lane, 2 LDS-transposed
-                                march                                                            */
-    int64_t nx, ny;          /* real cells of the block                                         */
-    double  dt, dx;          /* sweep time step (current_dt·factor) and cell size along axis    */
-    double  gamma;           /* perfect gas only                                                */
-    double  u_factor_low, v_factor_low, u_factor_high, v_factor_high;   /* BC factors per side  */
+    int32_t axis, scheme, limiter, projection, eos, nghost;
+    int32_t bc_low, bc_high;
+    int32_t exact, x_kernel;
+    int64_t nx, ny;
+    double  dt, dx, gamma;
+    double  u_factor_low, v_factor_low, u_factor_high, v_factor_high;
     const float *rho_in, *u_in, *v_in, *E_in;
     float *rho_out, *u_out, *v_out, *E_out;
-    float *p_out;            /* nullable: EOS pressure of the PRE-sweep state (real cells)      */
-    float *c_out;            /* nullable: EOS sound speed of the PRE-sweep state (real cells)   */
-    /* Fused dt/CFL reduction of the NEXT cycle (ref src/reductions.jl:2-53, src/solver.jl:298): when
-     * dt_cfl_out is non-NULL the sweep also reduces min(cfl_dx/max|u±c|, cfl_dy/max|v±c|) over the real
-     * cells, with the post-sweep u, v and the pre-sweep c — exactly what dtCFL_kernel reads at the start
-     * of the next cycle when this is the last sweep of a cycle — into *dt_cfl_out (one
-     * device double, written by a follow-up fold kernel on the same stream). */
-    float *dt_cfl_out; 
-    double  cfl_dx, cfl_dy;  /* GLOBAL cell sizes along x and y (ref src/reductions.jl:92)        */
-    /* Partial sweeps, for overlapping the halo exchange with compute: produce only the cells
-     * out_lo <= i < out_hi along the sweep axis (0-based real coordinates; out_hi == 0 means the whole
-     * block). The interior [LAG, n-LAG) needs no ghost cell and can run while the halos travel; the two
-     * LAG-wide boundary strips follow once the ghosts are in. dt_accumulate != 0: *dt_cfl_out =
-     * min(*dt_cfl_out, this launch's value) instead of overwriting it. */
+    float *p_out, *c_out;
+    float *dt_cfl_out;
+    double  cfl_dx, cfl_dy;
     int64_t out_lo, out_hi;
-    int32_t dt_accumulate;
-    int32_t reserved;
-} armon_sweep_desc_f32;   /* same layout; scalars stay double and are rounded to float inside */
+    int32_t dt_accumulate, reserved;
+} armon_sweep_desc_f32;
 
 ARMON_API int armon_hip_sweep_f32(armon_ctx*, const armon_sweep_desc_f32*);
 ARMON_API int armon_hip_tune_placement_f32(armon_ctx*, const armon_sweep_desc_f32* x_desc, const armon_sweep_desc_f32* y_desc,
