@@ -346,12 +346,8 @@ k_sweep_y(sweep_args a)
         so_off += pitchb;
     };
     auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 8
-        for (int t = t0; t < t1; t += 8) {
-#ifdef ARMON_Y_SYNC   // experiment: keep the waves of a workgroup on the same rows
-            if ((t & (ARMON_Y_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
-#endif
+        for (int t = t0; t < t1; t += 8)
             static_for(std::make_integer_sequence<int, 8>{}, [&](auto ph) { step(ph, checked, jb + t + decltype(ph)::value); });
-        }
     };
 
     const int T = je - jb;                                   // steps of the run
@@ -364,11 +360,7 @@ k_sweep_y(sweep_args a)
 
     // The block origin shift leaves the last workgroup of a row mostly past the last column: a wave with no
     // column at all skips the march (it still joins the block reduction below with neutral values).
-#ifdef ARMON_Y_SYNC
-    const bool wave_idle = false;
-#else
     const bool wave_idle = (int)(blockIdx.x * kYBlock + (threadIdx.x & ~63u)) - a.xshift >= nx;   // wave-uniform
-#endif
     if (!wave_idle) {
         static_for(std::make_integer_sequence<int, PF>{}, [&](auto k) { load(k, std::true_type{}); });
         run(std::true_type{}, 0, P < T8 ? P : T8);
