@@ -157,13 +157,17 @@ int make_tile_resources(tile_t& t)
     return ARMON_OK;
 }
 
-int ensure_face_buffers(tile_t& t, int side, size_t bytes)
+int ensure_face_buffers(armon_mgpu* g, tile_t& t, int side, size_t bytes)
 {
     if (bytes <= t.cap[side]) return ARMON_OK;
+    // growing is rare (the first exchange of a side, or a wider set of variables later): drain every stream of the group —
+    // a neighbour's transfer stream may still be reading the buffer that is about to be freed — then replace
+    for (tile_t& o : g->tiles) {
+        ARMON_HIP_TRY(hipSetDevice(o.device));
+        ARMON_HIP_TRY(hipStreamSynchronize(o.ctx->stream));
+        ARMON_HIP_TRY(hipStreamSynchronize(o.xfer));
+    }
     ARMON_HIP_TRY(hipSetDevice(t.device));
-    // growing is rare (first exchange of a side): drain both streams of the tile, then replace
-    ARMON_HIP_TRY(hipStreamSynchronize(t.ctx->stream));
-    ARMON_HIP_TRY(hipStreamSynchronize(t.xfer));
     if (t.send[side]) ARMON_HIP_TRY(hipFree(t.send[side]));
     if (t.recv[side]) ARMON_HIP_TRY(hipFree(t.recv[side]));
     t.send[side] = t.recv[side] = nullptr;
@@ -226,7 +230,7 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
             rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, &border, nullptr, &face);
             if (rc != ARMON_OK) return rc;
             const size_t bytes = (size_t)face * d[k].nghost * d[k].nvars * sizeof(T);
-            rc = ensure_face_buffers(t, s, bytes);
+            rc = ensure_face_buffers(g, t, s, bytes);
             if (rc != ARMON_OK) return rc;
             ARMON_HIP_TRY(hipSetDevice(t.device));
             // the previous message of this side must have left send[s] (in-process: the neighbour's copy event; RCCL:

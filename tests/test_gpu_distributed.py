@@ -157,9 +157,10 @@ def test_native_halo_exchange_moves_index_encoded_faces():
                 iy, ix = np.mgrid[0:ny, 0:nx]
                 a[g:g + ny, g:g + nx] = vi * 1e7 + (gy0 + iy) * NG[0] + (gx0 + ix)
                 grid.data[k].copy_from_host(a.ravel())
-        for axis in (Axis.X, Axis.Y):
-            group.exchange_start(axis, names)
-            group.exchange_finish(axis, names)
+        for subset in (names[:4], names):            # 4 variables first (the fused path's set), then 7: the face buffers grow
+            for axis in (Axis.X, Axis.Y):
+                group.exchange_start(axis, subset)
+                group.exchange_finish(axis, subset)
         group.wait()
         for p, grid in zip(group.params, group.grids):
             nx, ny = p.N
