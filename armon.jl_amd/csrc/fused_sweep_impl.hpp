@@ -1347,7 +1347,7 @@ extern "C" int ARMON_TUNE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, con
 // Same choice for a pool that holds NO state worth keeping (a host calls it BEFORE init_test writes the initial
 // condition): nothing is parked or restored, so the only transient memory is the caller's spare vectors. Each
 // candidate's four input vectors are filled with a uniform state (the sweeps' instruction stream does not depend on the
-// data) and timed like above; after 8 draws the search stops as soon as two of them lie within `tolerance` of the best
+// data) and timed like above; after 12 draws the search stops as soon as two of them lie within `tolerance` of the best
 // one while a draw at least 7 % slower has been seen as well (the good placements form a plateau), after
 // at most `tries` draws.
 namespace {
@@ -1415,7 +1415,7 @@ extern "C" int ARMON_CHOOSE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, c
             for (int k = 0; k < 8; k++) best[k] = idx[k];
         }
         // stop once the plateau of good placements has been hit twice — two draws within `tolerance` of the best —
-        // AND a draw at least 7 % slower has been seen too, after 8 draws at least: the X+Y times come in three
+        // AND a draw at least 7 % slower has been seen too, after 12 draws at least: the X+Y times come in three
         // levels (16384²: ≈5.65 / 6.17 / 6.45 ms) and two equal draws of the middle level must not end the search
         int near = 0;
         double worst = 0;
@@ -1423,7 +1423,7 @@ extern "C" int ARMON_CHOOSE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, c
             near += v <= best_ms * (1. + tolerance);
             worst = v > worst ? v : worst;
         }
-        if (tolerance > 0 && t >= 7 && near >= 2 && best_ms <= 0.93 * worst) { t++; break; }
+        if (tolerance > 0 && t >= 11 && near >= 2 && best_ms <= 0.93 * worst) { t++; break; }
     }
 #undef CHOOSE_TRY
     for (int k = 0; k < 8; k++) picks[k] = best[k];

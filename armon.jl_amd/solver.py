@@ -155,7 +155,7 @@ class BlockGrid:
 
         ``keep_state=False`` (what ``init_test`` does, BEFORE it writes the initial condition):
         ``armon_hip_choose_placement`` — the vectors hold nothing yet, candidates are timed on a uniform state, the
-        search may stop after 8 draws once two of them lie within 1 % of the best and 7 % under the worst; transient
+        search may stop after 12 draws once two of them lie within 1 % of the best and 7 % under the worst; transient
         memory = the 8 ``spare`` vectors only (17 GB at 16384²). The pool is deliberately small: among 12-16 vectors
         allocated one after the other about half of the random draws land on the fast level, among 32 one in twenty
         (profiles/r02_placement_pool_sizes.txt) — up to ``placement_tries`` = 32 draws make a miss unlikely.

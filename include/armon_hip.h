@@ -324,7 +324,7 @@ ARMON_API int armon_hip_tune_placement(armon_ctx*, const armon_sweep_desc* x_des
 
 /* The same choice for a pool that holds NO state yet — call it BEFORE init_test: nothing has to be parked or restored,
  * so the only transient memory is the caller's own spare vectors (n_pool - 8 of them). Candidates are timed on a uniform
- * state the call writes itself (every vector of the pool is overwritten); after 8 draws the search stops early once two
+ * state the call writes itself (every vector of the pool is overwritten); after 12 draws the search stops early once two
  * of them lie within `tolerance` (e.g. 0.01; 0 = never) of the best seen and a draw >= 7 % slower has been seen too,
  * after at most `tries`. picks[role] as above (roles 0..3:
  * where init_test should put rho,u,v,E; 4..7: their ping-pong partners); *tries_done (nullable) = draws timed. */
