@@ -259,3 +259,16 @@ def test_file_paths_and_time_step_file(tmp_path):
     aio.write_time_step_file(p, 0.00431962688696710, "dt")
     assert open(tmp_path / "out" / "dt").read() == " 4.31962688696709961e-03\n"      # %#24.17e
     assert aio.read_time_step_file(p, "dt") == 0.00431962688696710
+
+
+def test_bench_refuses_an_impossible_process_grid_before_touching_a_gpu():
+    """bench.py --grid must multiply to the number of ranks (checked before any device is created), and N > 1 without
+    the launcher is refused with a message instead of running something else."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--grid", "2x2"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "cannot form that process grid" in r.stderr and r.stdout == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "torch.distributed.run" in r.stderr and r.stdout == ""
