@@ -18,10 +18,10 @@ def test_header_is_plain_c_and_cxx(tmp_path, compiler, std):
                     "-fsyntax-only", str(src)], check=True)
 
 
-def build_example(tmp_path):
-    exe = str(tmp_path / "native_cycle")
+def build_example(tmp_path, name="native_cycle"):
+    exe = str(tmp_path / name)
     subprocess.run(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-Werror",
-                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "native_cycle.c"), "-o", exe,
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"), "-o", exe,
                     "-L", os.path.join(ROOT, "armon.jl_amd"), "-larmon_hip",
                     "-Wl,-rpath," + os.path.join(ROOT, "armon.jl_amd"), "-lm"], check=True)
     return exe
@@ -29,6 +29,7 @@ def build_example(tmp_path):
 
 def test_native_example_builds(tmp_path):
     build_example(tmp_path)
+    build_example(tmp_path, "native_tiles")
 
 
 @pytest.mark.gpu
@@ -48,3 +49,28 @@ def test_native_example_matches_the_python_host(tmp_path):
     pm1, pe1 = conservation_vars(params, grid)
     assert (m0, e0) == (pm0, pe0)
     assert (m1, e1) == (pm1, pe1)          # same kernels, same dt rule: the same bits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,px,py", [(640, 2, 2), (517, 3, 1), (400, 1, 2)])
+def test_native_tiles_example_matches_the_python_tile_group(tmp_path, n, px, py):
+    """examples/native_tiles.c — the multi-GPU entry points (armon_hip_mgpu_init, halo_exchange_start/finish,
+    dt_allreduce) driven from plain C, every tile on device 0 — ends on the same global mass and energy, bit for bit, as
+    multi_tile.TileGroup on the same tile grid (same kernels, same exchange, same dt rule, same order of the sums)."""
+    from armon_amd.multi_tile import TileGroup
+    cycles = 30
+    out = subprocess.run([build_example(tmp_path, "native_tiles"), str(n), str(px), str(py), str(cycles)], check=True,
+                         capture_output=True, text=True).stdout
+    m = re.search(r"mass (\S+) -> (\S+), energy (\S+) -> (\S+)", out)
+    assert m, out
+    m0, m1, e0, e1 = (float(x.rstrip(",")) for x in m.groups())
+    group = TileGroup((px, py), test="Sod", N=(n, n), maxcycle=cycles, maxtime=1e9, silent=5)
+    try:
+        group.init_test()
+        pm0, pe0 = group.conservation_vars()
+        group.time_loop()
+        pm1, pe1 = group.conservation_vars()
+    finally:
+        group.close()
+    assert (m0, e0) == (pm0, pe0)
+    assert (m1, e1) == (pm1, pe1)
