@@ -7,13 +7,14 @@
 # struct mirrors (CRange, CBlockData, SweepDesc, HaloDesc) with the ctypes structures field by field.
 # The ABI itself is exercised end to end by the Python host (tests/) and by examples/native_cycle.c.
 #
-# Install: copy to Armon.jl/ext/, declare it in Project.toml ([weakdeps]/[extensions] ArmonHIPNative = "Libdl"), then
+# Install: copy to Armon.jl/ext/, declare it in Project.toml ([weakdeps]/[extensions] ArmonHIPNative = "Libdl" (MPI is already a dependency of Armon)), then
 #   ArmonParameters(; use_gpu=true, device=:HIP_native, use_cache_blocking=false, async_cycle=false,
 #                     armon_hip_lib="/path/libarmon_hip.so", ...)
 module ArmonHIPNative
 
 using Armon
 using Libdl
+import MPI
 import Armon: ArmonParameters, BlockGrid, BlockData, DomainRange, SolverState, LocalTaskBlock, Side, Axis
 import Armon: create_device, init_backend, device_array_type, host_array_type, device_memory_info,
               print_device_info, solver_error, block_device_data, block_domain_range, stride_along,
@@ -76,6 +77,14 @@ Base.copyto!(dst::HIPVector{T}, src::Array{T}) where T = (check(ccall(fn(:armon_
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), dst.dev.ctx, dst.ptr, src, sizeof(src), 1)); dst)
 Base.copyto!(dst::HIPVector{T}, src::HIPVector{T}) where T = (check(ccall(fn(:armon_hip_memcpy), Cint,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), dst.dev.ctx, dst.ptr, src.ptr, sizeof(src), 3)); dst)
+
+# ---- gpu_aware=true: the reference types its MPI buffers as the DEVICE array (ref src/blocking/block_grid.jl:72,
+# src/blocking/blocks.jl:188-201: MPI.Buffer(B(undef, size)) → MPI.Send_init / Recv_init), packs into them with
+# pack_to_array! on the device, waits, then MPI.Startall (ref src/halo_exchange.jl:242-248). A ROCm-aware MPI takes the
+# device pointer as it is — the same three methods MPI.jl's own AMDGPU extension defines for ROCArray:
+MPI.Buffer(v::HIPVector{T}) where T = MPI.Buffer(v, Cint(length(v)), MPI.Datatype(T))
+Base.cconvert(::Type{MPI.MPIPtr}, v::HIPVector) = v
+Base.unsafe_convert(::Type{MPI.MPIPtr}, v::HIPVector) = reinterpret(MPI.MPIPtr, v.ptr)
 
 # ---- backend hooks (ref src/parameters.jl:751-802,921-951,1031-1038) -----------------------------------------------
 function create_device(::Val{:HIP_native})
