@@ -275,10 +275,17 @@ class NativeRcclExchanger:
         self.params, self.grid, self._L = params, grid, L
         group = params.global_comm
         buf = C.create_string_buffer(_lib.MGPU_ID_BYTES)
+        obj = [None]
         if params.rank == 0:
-            check(L.armon_hip_mgpu_unique_id(buf))
-        obj = [bytes(buf.raw)]
+            # a failure here (no RCCL in the process) still has to reach the broadcast every other rank is waiting in
+            try:
+                check(L.armon_hip_mgpu_unique_id(buf))
+                obj = [bytes(buf.raw)]
+            except _lib.SolverException as e:
+                obj = [str(e)]
         dist.broadcast_object_list(obj, src=0, group=group)
+        if not isinstance(obj[0], bytes):
+            raise _lib.SolverException("cpp", f"rank 0 could not create the RCCL ids: {obj[0]}")
         ident = C.create_string_buffer(obj[0], _lib.MGPU_ID_BYTES)
         dev = params.device                     # the tile's kernels keep running on the context the run already uses
         self.handle = C.c_void_p()
