@@ -206,3 +206,50 @@ def test_config5_bizarrium_16384_tuned(oracle):
         assert np.array_equal(a, np.broadcast_to(a[0:1], a.shape)), f"{k}: rows differ"
         assert np.abs(a[0] - o).max() <= 1e-11 * np.abs(o).max(), k
         del a
+
+
+@pytest.mark.parametrize("test,shape,mode", [
+    ("Sod", (32768, 16384), "fused-tuned"),      # BASELINE config 4's global grid on ONE GPU: 4.3 GB per vector
+    ("Sod", (32768, 16384), "staged"),
+    ("Sod_y", (16384, 32768), "fused-exact"),
+    ("Bizarrium", (32768, 32768), "fused-tuned"),   # config 5's global grid on ONE GPU: 8.6 GB per vector, 172 GB in all
+])
+def test_vectors_beyond_4GiB(oracle, test, shape, mode):
+    """Maximum sizes: 537 M cells per vector (> 2³² bytes — every 32-bit byte offset in the kernels has to be relative
+    to something close), non-square cells (the domain stays 1 × 1). Same properties as at 16384²: identical lines,
+    the common line equal to the oracle's strip (bit for bit in exact arithmetic), dt, conservation."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, conservation_vars, init_test, time_loop
+    nx, ny = shape
+    along_x = test != "Sod_y"
+    n_strip = (nx, 8) if along_x else (8, ny)
+    ds = (1., 8. / ny) if along_x else (8. / nx, 1.)
+    cycles = 3
+    orun, f = oracle.solve(test=test, N=n_strip, domain_size=ds, maxcycle=cycles, threads=8)
+    params = armon_amd.ArmonParameters(test=test, N=shape, maxcycle=cycles, silent=5,
+                                       use_fused_sweep=mode != "staged", exact_arithmetic=mode != "fused-tuned")
+    grid = BlockGrid(params)
+    assert grid.data["rho"].nbytes > 1 << 32
+    init_test(params, grid)
+    m0, e0 = conservation_vars(params, grid)
+    time_, dt, ncyc, _, _ = time_loop(params, grid)
+    m1, e1 = conservation_vars(params, grid)
+    if test != "Bizarrium":                       # Bizarrium has an inflow boundary (ref src/tests.jl:48-49)
+        assert abs(m1 - m0) <= 1e-11 * abs(m0) and abs(e1 - e0) <= 1e-11 * abs(e0)
+    assert ncyc == orun.cycles == cycles
+    exact = mode != "fused-tuned"
+    if exact:
+        assert dt == orun.last_dt and time_ == orun.final_time
+    else:
+        assert abs(dt - orun.last_dt) <= 1e-12 * orun.last_dt
+    for k in ("rho", "u" if along_x else "v", "E"):
+        a = grid.real_view(grid.data[k].to_host())
+        o = oracle.real_view(f[k], n_strip[0], n_strip[1], G)
+        line = a[0:1] if along_x else a[:, 0:1]
+        assert np.array_equal(a, np.broadcast_to(line, a.shape)), f"{k}: lines differ"
+        oline = o[0] if along_x else o[:, 0]
+        if exact:
+            assert np.array_equal(line.ravel(), oline), k
+        else:
+            assert np.abs(line.ravel() - oline).max() <= 1e-11 * np.abs(oline).max(), k
+        del a
