@@ -253,3 +253,31 @@ def test_vectors_beyond_4GiB(oracle, test, shape, mode):
         else:
             assert np.abs(line.ravel() - oline).max() <= 1e-11 * np.abs(oline).max(), k
         del a
+
+
+@pytest.mark.parametrize("P,shape,test", [((2, 2), (32768, 16384), "Sod"), ((4, 2), (32768, 32768), "Bizarrium")],
+                         ids=["config4", "config5"])
+def test_baseline_tile_configurations_at_full_size(P, shape, test):
+    """BASELINE configs 4 and 5 as they are written — Sod 32768×16384 on 2×2 tiles of 16384×8192, Bizarrium 32768² on
+    4×2 tiles of 8192×16384 — through the library's multi-GPU entry points (armon_hip_mgpu_init, halo_exchange_start /
+    finish around the interior sweeps, dt_allreduce), every tile on this one GPU: the tiles together must hold the same
+    bits as the single block of the same grid (itself held against the oracle above), with the same dt and time."""
+    import gc
+    import armon_amd
+    from armon_amd.multi_tile import TileGroup
+    kw = dict(test=test, N=shape, maxcycle=3, silent=5)          # tuned arithmetic: what bench.py runs
+    ref = armon_amd.armon(armon_amd.ArmonParameters(return_data=True, **kw))
+    want = (ref.cycles, ref.last_dt, ref.final_time)
+    full = {k: ref.data.real_view(ref.data.data[k].to_host()) for k in ("rho", "E")}
+    del ref
+    gc.collect()                                                  # 86 / 172 GB back before the tiles take as much
+    group = TileGroup(P, **kw)
+    try:
+        assert [tuple(p.N) for p in group.params][0] == (shape[0] // P[0], shape[1] // P[1])
+        stats = group.run()
+        assert (stats.cycles, stats.last_dt, stats.final_time) == want
+        got = group.gather(("rho", "E"))
+        for k in ("rho", "E"):
+            assert np.array_equal(got[k], full[k]), k
+    finally:
+        group.close()
