@@ -69,3 +69,71 @@ for pattern in args.patterns.split(","):
             v.free()
     else:
         slab.free()
+
+# ---- windows along ONE large slab: does the level depend on WHERE in the allocation the 8 vectors lie? -----------------
+if os.environ.get("SLAB_WINDOWS"):
+    K = int(os.environ["SLAB_WINDOWS"])              # vectors' worth of slab, e.g. 96 → 200 GB
+    slab = DeviceArray(dev, K * S, "uint8")
+    args.tries = 6
+    for w in range(0, K - 8 + 1, 4):
+        ptrs = [slab.ptr + (w + k) * S + offsets("rand", k) for k in range(8)]
+        assert ptrs[-1] + nbytes <= slab.ptr + K * S, "vectors must lie inside the slab"
+        t, picks = run(ptrs)
+        print(f"window at {w * S / 2**30:6.1f} GiB: " + " ".join(f"{v:.2f}" for v in t), flush=True)
+    slab.free()
+
+# ---- uniform stride inside one slab: X + Y sweep time against the stride's residue modulo 16 MiB, at several bases -----
+if os.environ.get("SLAB_STRIDES"):
+    GiB = 1 << 30
+    bases = (0, 1 * GiB, 5 * GiB, 22 * GiB)
+    slab_bytes = 8 * (2064 + 48) * MiB + bases[-1] + GiB + 64 * MiB
+    slab = DeviceArray(dev, slab_bytes, "uint8")
+    origin = -slab.ptr % GiB                                  # 1-GiB aligned virtual address
+    args.tries = 1                                            # the identity assignment only: roles in slab order
+    print(f"slab VA {slab.ptr:#x}; columns: base +0, +1 GiB, +5 GiB, +22 GiB; X+Y ms of the identity assignment")
+    for r in list(range(0, 32)) + [46, 47, 48]:
+        stride = (2064 + r) * MiB
+        row = []
+        for b in bases:
+            ptrs = [slab.ptr + origin + b + k * stride for k in range(8)]
+            assert ptrs[-1] + nbytes <= slab.ptr + slab_bytes and stride >= nbytes, "vectors must lie inside the slab"
+            t, _ = run(ptrs)
+            row.append(t[0])
+        print(f"stride 2064 + {r:2d} MiB (≡ {r % 16:2d} mod 16): " + " ".join(f"{v:.2f}" for v in row), flush=True)
+    slab.free()
+
+# ---- wide stride scan with the real sweeps: 2 GiB ... 4 GiB in 48-MiB steps, roles in slab order and interleaved --------
+if os.environ.get("SLAB_WIDE"):
+    GiB = 1 << 30
+    bases = (0, 5 * GiB)
+    t_max = 4224
+    slab_bytes = 8 * t_max * MiB + bases[-1] + GiB + 64 * MiB
+    slab = DeviceArray(dev, slab_bytes, "uint8")
+    origin = -slab.ptr % GiB
+    args.tries = 1
+    print(f"slab VA {slab.ptr:#x}; X+Y ms: [roles in slab order @base, @base+5GiB] [reads on even, writes on odd @base, @base+5GiB]")
+    for t_mib in range(2064, t_max + 1, 48):
+        stride = t_mib * MiB
+        row = []
+        for order in ((0, 1, 2, 3, 4, 5, 6, 7), (0, 2, 4, 6, 1, 3, 5, 7)):
+            for b in bases:
+                ptrs = [slab.ptr + origin + b + k * stride for k in order]
+                assert max(ptrs) + nbytes <= slab.ptr + slab_bytes and stride >= nbytes, "vectors must lie inside the slab"
+                t, _ = run(ptrs)
+                row.append(t[0])
+        print(f"stride {t_mib:5d} MiB (mod 2 GiB = {t_mib % 2048:4d}): " + " ".join(f"{v:.2f}" for v in row), flush=True)
+    slab.free()
+
+# ---- 16 vectors at a uniform stride in one slab, the same 24 role assignments for every residue of the stride -----------
+if os.environ.get("SLAB_RESIDUES"):
+    args.tries = 24
+    for t_mib in (2054, 2066, 2062, 2058, 2052, 2060, 2064, 2056):
+        stride = t_mib * MiB
+        slab_bytes = 16 * stride + 64 * MiB
+        slab = DeviceArray(dev, slab_bytes, "uint8")
+        ptrs = [slab.ptr + k * stride for k in range(16)]
+        assert max(ptrs) + nbytes <= slab.ptr + slab_bytes and stride >= nbytes, "vectors must lie inside the slab"
+        t, picks = run(ptrs)
+        fast = sum(v <= 5.85 for v in t)
+        print(f"stride {t_mib} MiB (≡ {t_mib % 16:2d} mod 16) fast {fast:2d}/24: " + " ".join(f"{v:.2f}" for v in t) + f"  best {picks}", flush=True)
+        slab.free()
