@@ -328,9 +328,26 @@ __global__ void k_min_broadcast(T* __restrict__ slots, int stride, int n)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         T m = slots[0];
-        for (int k = 1; k < n; k++) m = slots[k * stride] < m ? slots[k * stride] : m;
+        for (int k = 1; k < n; k++) m = (slots[k * stride] < m || slots[k * stride] != slots[k * stride]) ? slots[k * stride] : m;
         for (int k = 0; k < n; k++) slots[k * stride] = m;
     }
+}
+
+// every tile on ONE device (up to 64 of them): lane k reads tile k's scalar, the wave folds, lane k writes the minimum back
+constexpr int kMaxDirect = 64;
+struct dt_ptrs { void* p[kMaxDirect]; };
+template <typename T>
+__global__ void __launch_bounds__(64) k_min_broadcast_direct(dt_ptrs d, int n)
+{
+    const int lane = threadIdx.x;
+    T* mine = static_cast<T*>(d.p[lane < n ? lane : 0]);
+    T m = *mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(m, off, 64);
+        m = (o < m || o != o) ? o : m;          // a NaN anywhere must reach the host's validity check
+    }
+    if (lane < n) *mine = m;
 }
 
 template <typename T>
@@ -347,8 +364,28 @@ int dt_allreduce(armon_mgpu* g, T* const* dt_dev)
         return ARMON_OK;
     }
     if (nt == 1) return ARMON_OK;
-    // gather on tile 0's device (its transfer stream), fold, scatter back; every compute stream waits for its value only
     tile_t& root = g->tiles[0];
+    bool one_device = nt <= (size_t)kMaxDirect;
+    for (size_t k = 0; k < nt; k++) one_device = one_device && g->tiles[k].device == root.device;
+    if (one_device) {
+        // one kernel on tile 0's transfer stream instead of 2·nt serialized copies (the chain between two cycles)
+        ARMON_HIP_TRY(hipSetDevice(root.device));
+        dt_ptrs d;
+        for (size_t k = 0; k < nt; k++) {
+            tile_t& t = g->tiles[k];
+            d.p[k] = dt_dev[k];
+            ARMON_HIP_TRY(hipEventRecord(t.e_red, t.ctx->stream));
+            ARMON_HIP_TRY(hipStreamWaitEvent(root.xfer, t.e_red, 0));
+        }
+        hipLaunchKernelGGL(k_min_broadcast_direct<T>, dim3(1), dim3(64), 0, root.xfer, d, (int)nt);
+        int rc = check_launch("min_broadcast_direct");
+        if (rc != ARMON_OK) return rc;
+        ARMON_HIP_TRY(hipEventRecord(g->e_red_done, root.xfer));
+        for (size_t k = 0; k < nt; k++) ARMON_HIP_TRY(hipStreamWaitEvent(g->tiles[k].ctx->stream, g->e_red_done, 0));
+        return ARMON_OK;
+    }
+    // several devices: gather on tile 0's device (its transfer stream), fold, scatter back; every compute stream waits
+    // for its value only
     constexpr int stride = sizeof(double) / sizeof(T);       // one 8-byte slot per tile
     T* slots = reinterpret_cast<T*>(g->red_buf);
     for (size_t k = 0; k < nt; k++) {
