@@ -130,6 +130,10 @@ SIGNATURES = {
     "armon_hip_halo_exchange_finish": (_ci, [_vp, _ci, C.POINTER(HaloDesc)]),
     "armon_hip_halo_exchange": (_ci, [_vp, _ci, C.POINTER(HaloDesc)]),
     "armon_hip_dt_allreduce": (_ci, [_vp, C.POINTER(_vp)]),
+    "armon_hip_mgpu_edge_ctx": (_vp, [_vp, _ci]),
+    "armon_hip_mgpu_edge_dt": (_vp, [_vp, _ci]),
+    "armon_hip_halo_exchange_finish_edge": (_ci, [_vp, _ci, C.POINTER(HaloDesc)]),
+    "armon_hip_mgpu_edge_join": (_ci, [_vp, C.POINTER(_vp)]),
     "armon_hip_mgpu_allreduce_host": (_ci, [_vp, _ci, _ci, C.POINTER(_dbl)]),
     "armon_hip_halo_ranges": (_ci, [_i64, _i64, _ci, _ci, C.POINTER(Range), C.POINTER(Range), C.POINTER(_i64)]),
 }
@@ -153,7 +157,8 @@ def _add_f32_signatures():
             else:
                 conv.append(a)
         SIGNATURES["armon_hip_" + name + "_f32"] = (res, conv)
-    for name in ("halo_exchange_start", "halo_exchange_finish", "halo_exchange", "dt_allreduce"):
+    for name in ("halo_exchange_start", "halo_exchange_finish", "halo_exchange", "dt_allreduce",
+                 "halo_exchange_finish_edge", "mgpu_edge_join"):
         SIGNATURES["armon_hip_" + name + "_f32"] = SIGNATURES["armon_hip_" + name]
     SIGNATURES["armon_hip_sweep_f32"] = SIGNATURES["armon_hip_sweep"]
     SIGNATURES["armon_hip_tune_placement_f32"] = SIGNATURES["armon_hip_tune_placement"]

@@ -23,6 +23,7 @@
 // armon_hip_pack_to_array / armon_hip_unpack_from_array.
 #include "common.hpp"
 
+#include <cmath>
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and enums only: every entry point is resolved with dlsym
 
@@ -96,6 +97,9 @@ int load_rccl()
     } while (0)
 
 constexpr int kSides = 4;
+// Bit pattern of an unused edge scalar, neutral for the minimum in BOTH precisions: +inf as a float, 1.4e306 as (half of)
+// a double — a group may run fp64 and fp32 problems one after the other.
+constexpr unsigned kEdgeNeutral = 0x7F800000u;
 inline int opposite(int side) { return side ^ 1; }            // Left<->Right, Bottom<->Top (ARMON_SIDE_* order)
 inline int first_side(int axis) { return axis == ARMON_AXIS_X ? ARMON_SIDE_LEFT : ARMON_SIDE_BOTTOM; }
 
@@ -112,6 +116,11 @@ struct tile_t {
     bool rec_recv[kSides] = {}, rec_unpack[kSides] = {};
     size_t inflight[kSides] = {};                // bytes posted by start, 0 = nothing pending
     hipEvent_t e_red = nullptr;                  // dt scalar ready on the compute stream
+    // "edge" work — unpack + the LAG-wide strips next to the remote sides — on the TRANSFER stream, concurrent with the
+    // interior sweep on the compute stream (they read the same input state and write disjoint cells)
+    armon_ctx* edge = nullptr;                   // a context on xfer (own reduction scratch)
+    hipEvent_t e_edge = nullptr;                 // edge work of the current sweep done
+    double* edge_dt = nullptr;                   // [2] device scalars: the strips' CFL steps (+inf when unused)
 };
 
 }  // namespace
@@ -154,6 +163,12 @@ int make_tile_resources(tile_t& t)
         ARMON_HIP_TRY(hipEventCreateWithFlags(&t.e_unpack[s], hipEventDisableTiming));
     }
     ARMON_HIP_TRY(hipEventCreateWithFlags(&t.e_red, hipEventDisableTiming));
+    ARMON_HIP_TRY(hipEventCreateWithFlags(&t.e_edge, hipEventDisableTiming));
+    int rc = armon_hip_init(t.device, (void*)t.xfer, &t.edge);
+    if (rc != ARMON_OK) return rc;
+    ARMON_HIP_TRY(hipMalloc((void**)&t.edge_dt, 2 * sizeof(double)));
+    const unsigned neutral[4] = {kEdgeNeutral, kEdgeNeutral, kEdgeNeutral, kEdgeNeutral};
+    ARMON_HIP_TRY(hipMemcpy(t.edge_dt, neutral, sizeof neutral, hipMemcpyHostToDevice));
     return ARMON_OK;
 }
 
@@ -295,7 +310,7 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
 }
 
 template <typename T>
-int exchange_finish(armon_mgpu* g, int axis, const armon_halo_desc* d)
+int exchange_finish(armon_mgpu* g, int axis, const armon_halo_desc* d, bool on_edge = false)
 {
     int rc = check_desc(g, axis, d);
     if (rc != ARMON_OK) return rc;
@@ -311,11 +326,13 @@ int exchange_finish(armon_mgpu* g, int axis, const armon_halo_desc* d)
             ARMON_REQUIRE((size_t)face * d[k].nghost * d[k].nvars * sizeof(T) == t.inflight[s],
                           "tile %zu: finish does not match the exchange that was started", k);
             ARMON_HIP_TRY(hipSetDevice(t.device));
-            ARMON_HIP_TRY(hipStreamWaitEvent(t.ctx->stream, t.e_recv[s], 0));
-            rc = unpack<T>(t.ctx, ghost, d[k].nghost, face, static_cast<const T*>(t.recv[s]), d[k].nvars,
+            // on the transfer stream the unpack simply follows the receive; on the compute stream it waits for it
+            armon_ctx* c = on_edge ? t.edge : t.ctx;
+            if (!on_edge) ARMON_HIP_TRY(hipStreamWaitEvent(c->stream, t.e_recv[s], 0));
+            rc = unpack<T>(c, ghost, d[k].nghost, face, static_cast<const T*>(t.recv[s]), d[k].nvars,
                            reinterpret_cast<T* const*>(d[k].vars));
             if (rc != ARMON_OK) return rc;
-            ARMON_HIP_TRY(hipEventRecord(t.e_unpack[s], t.ctx->stream));
+            ARMON_HIP_TRY(hipEventRecord(t.e_unpack[s], c->stream));
             t.rec_unpack[s] = true;
             t.inflight[s] = 0;
         }
@@ -331,6 +348,41 @@ __global__ void k_min_broadcast(T* __restrict__ slots, int stride, int n)
         for (int k = 1; k < n; k++) m = (slots[k * stride] < m || slots[k * stride] != slots[k * stride]) ? slots[k * stride] : m;
         for (int k = 0; k < n; k++) slots[k * stride] = m;
     }
+}
+
+// dst = min(dst, e[0], e[1]), then both scalars neutral again (NaN wins, so that the host's validity check sees it)
+template <typename T>
+__global__ void k_fold_edge_dt(T* __restrict__ dst, T* __restrict__ e)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        T m = *dst;
+        for (int k = 0; k < 2; k++) {
+            const T v = e[k];
+            m = (v < m || v != v) ? v : m;
+        }
+        *dst = m;
+        unsigned* w = reinterpret_cast<unsigned*>(e);
+        for (int k = 0; k < 4; k++) w[k] = kEdgeNeutral;
+    }
+}
+
+template <typename T>
+int edge_join(armon_mgpu* g, T* const* dt_dev)
+{
+    ARMON_REQUIRE(g, "NULL argument");
+    for (size_t k = 0; k < g->tiles.size(); k++) {
+        tile_t& t = g->tiles[k];
+        ARMON_HIP_TRY(hipSetDevice(t.device));
+        ARMON_HIP_TRY(hipEventRecord(t.e_edge, t.xfer));
+        ARMON_HIP_TRY(hipStreamWaitEvent(t.ctx->stream, t.e_edge, 0));
+        if (dt_dev) {
+            ARMON_REQUIRE(dt_dev[k], "dt_dev[%zu] is NULL", k);
+            hipLaunchKernelGGL(k_fold_edge_dt<T>, dim3(1), dim3(64), 0, t.ctx->stream, dt_dev[k], reinterpret_cast<T*>(t.edge_dt));
+            int rc = check_launch("fold_edge_dt");
+            if (rc != ARMON_OK) return rc;
+        }
+    }
+    return ARMON_OK;
 }
 
 // every tile on ONE device (up to 64 of them): lane k reads tile k's scalar, the wave folds, lane k writes the minimum back
@@ -573,6 +625,9 @@ int armon_hip_mgpu_destroy(armon_mgpu* g)
             if (t.e_unpack[s]) (void)hipEventDestroy(t.e_unpack[s]);
         }
         if (t.e_red) (void)hipEventDestroy(t.e_red);
+        if (t.e_edge) (void)hipEventDestroy(t.e_edge);
+        if (t.edge_dt) (void)hipFree(t.edge_dt);
+        if (t.edge) (void)armon_hip_destroy(t.edge);          // before the stream it borrows
         if (t.xfer) (void)hipStreamDestroy(t.xfer);
         if (t.ctx && t.owns_ctx) (void)armon_hip_destroy(t.ctx);
     }
@@ -616,6 +671,22 @@ int armon_hip_halo_exchange_f32(armon_mgpu* g, int axis, const armon_halo_desc* 
     int rc = exchange_start<float>(g, axis, tiles);
     return rc != ARMON_OK ? rc : exchange_finish<float>(g, axis, tiles);
 }
+
+// ---- edge stream: unpack and boundary strips concurrent with the interior sweep -----------------------------------------
+armon_ctx* armon_hip_mgpu_edge_ctx(armon_mgpu* g, int local_tile)
+{
+    if (!g || local_tile < 0 || local_tile >= (int)g->tiles.size()) return nullptr;
+    return g->tiles[local_tile].edge;
+}
+void* armon_hip_mgpu_edge_dt(armon_mgpu* g, int local_tile)
+{
+    if (!g || local_tile < 0 || local_tile >= (int)g->tiles.size()) return nullptr;
+    return g->tiles[local_tile].edge_dt;
+}
+int armon_hip_halo_exchange_finish_edge(armon_mgpu* g, int axis, const armon_halo_desc* tiles) { return exchange_finish<double>(g, axis, tiles, true); }
+int armon_hip_halo_exchange_finish_edge_f32(armon_mgpu* g, int axis, const armon_halo_desc* tiles) { return exchange_finish<float>(g, axis, tiles, true); }
+int armon_hip_mgpu_edge_join(armon_mgpu* g, double* const* dt_dev) { return edge_join<double>(g, dt_dev); }
+int armon_hip_mgpu_edge_join_f32(armon_mgpu* g, float* const* dt_dev) { return edge_join<float>(g, dt_dev); }
 
 int armon_hip_dt_allreduce(armon_mgpu* g, double* const* dt_dev) { return dt_allreduce<double>(g, dt_dev); }
 int armon_hip_dt_allreduce_f32(armon_mgpu* g, float* const* dt_dev) { return dt_allreduce<float>(g, dt_dev); }

@@ -51,7 +51,7 @@ class TileGroup:
         self._L = L
         for k in ("use_MPI", "device_id", "P"):
             options.pop(k, None)
-        self.params, self.grids = [], []
+        self.params, self.grids, self._edge_ctx, self._edge_dt = [], [], [], []
         for r in range(nt):
             ctx = C.c_void_p(L.armon_hip_mgpu_ctx(self.handle, r))
             p = ArmonParameters(**options, tile_of=(r, self.P), ctx=ctx, device_id=ids[r])
@@ -62,6 +62,8 @@ class TileGroup:
             assert [p.neighbours[s] for s in (Side.Left, Side.Right, Side.Bottom, Side.Top)] == list(nb)
             self.params.append(p)
             self.grids.append(S.BlockGrid(p))
+            self._edge_ctx.append(C.c_void_p(L.armon_hip_mgpu_edge_ctx(self.handle, r)))
+            self._edge_dt.append(int(L.armon_hip_mgpu_edge_dt(self.handle, r)))
         self.root = self.params[0]
         self.global_dt = self.grids[0].global_dt
         for g in self.grids:
@@ -98,6 +100,13 @@ class TileGroup:
 
     def exchange_finish(self, axis, names):
         check(self._fn("halo_exchange_finish")(self.handle, int(axis) - 1, _halo_descs(self.params, self.grids, names)))
+
+    def exchange_finish_edge(self, axis, names):
+        check(self._fn("halo_exchange_finish_edge")(self.handle, int(axis) - 1, _halo_descs(self.params, self.grids, names)))
+
+    def edge_join(self, with_dt):
+        ptrs = (C.c_void_p * len(self.grids))(*[g.dt_scalar.ptr for g in self.grids]) if with_dt else None
+        check(self._fn("mgpu_edge_join")(self.handle, ptrs))
 
     def dt_allreduce(self):
         ptrs = (C.c_void_p * len(self.grids))(*[g.dt_scalar.ptr for g in self.grids])
@@ -142,17 +151,29 @@ class TileGroup:
                 lo, hi = (lag if lo_r else 0), (n - lag if hi_r else n)
                 S.fused_sweep(p, g, axis, dt, dx, out_range=(lo, hi), swap=False, **emit)
                 late.append((p, g, (lo, hi, n)))
+        # Edge stream (default): unpack and strips run on each tile's transfer stream, concurrent with the interiors,
+        # when every tile with a remote side overlaps (a tile too small to have an interior sweeps after the unpack, on
+        # its compute stream, so then the whole group takes the in-order form).
+        on_edge = any_remote and self.root.edge_stream and all(part is not None for _, _, part in late)
         if any_remote:
-            self.exchange_finish(axis, S.STATE_VARS)
+            (self.exchange_finish_edge if on_edge else self.exchange_finish)(axis, S.STATE_VARS)
+        sz = np.dtype(self.root.data_type).itemsize
         for p, g, part in late:
             if part is None:
                 S.fused_sweep(p, g, axis, dt, dx, swap=False, **emit)
                 continue
             lo, hi, n = part
-            if lo > 0:
-                S.fused_sweep(p, g, axis, dt, dx, out_range=(0, lo), swap=False, dt_accumulate=True, **emit)
-            if hi < n:
-                S.fused_sweep(p, g, axis, dt, dx, out_range=(hi, n), swap=False, dt_accumulate=True, **emit)
+            k = self.params.index(p)
+            for side, rng in enumerate(((0, lo), (hi, n))):
+                if rng[0] == rng[1]:
+                    continue
+                if on_edge:
+                    S.fused_sweep(p, g, axis, dt, dx, out_range=rng, swap=False, ctx=self._edge_ctx[k],
+                                  dt_out=self._edge_dt[k] + side * sz, **emit)
+                else:
+                    S.fused_sweep(p, g, axis, dt, dx, out_range=rng, swap=False, dt_accumulate=True, **emit)
+        if on_edge:
+            self.edge_join(bool(emit.get("emit_dt")))
         for g in self.grids:
             g.swap_state()
 
@@ -296,6 +317,8 @@ class NativeRcclExchanger:
         check(L.armon_hip_mgpu_tile_info(self.handle, 0, C.byref(rank), C.byref(coords), C.byref(nb)))
         assert rank.value == params.rank and tuple(coords) == params.cart_coords
         assert [params.neighbours[s] for s in (Side.Left, Side.Right, Side.Bottom, Side.Top)] == list(nb)
+        self.edge_ctx = C.c_void_p(L.armon_hip_mgpu_edge_ctx(self.handle, 0))      # this tile's transfer stream as a context
+        self.edge_dt = int(L.armon_hip_mgpu_edge_dt(self.handle, 0))
 
     def _fn(self, name):
         return getattr(self._L, "armon_hip_" + name + self.params.suffix)
@@ -316,6 +339,17 @@ class NativeRcclExchanger:
             return
         axis, names = handle
         check(self._fn("halo_exchange_finish")(self.handle, int(axis) - 1, self._desc(names)))
+
+    def finish_edge(self, handle):
+        """Unpack on the transfer stream (no wait on the compute stream): the strips follow there, then ``edge_join``."""
+        if handle is None:
+            return
+        axis, names = handle
+        check(self._fn("halo_exchange_finish_edge")(self.handle, int(axis) - 1, self._desc(names)))
+
+    def edge_join(self, dt_scalar=None):
+        ptrs = (C.c_void_p * 1)(dt_scalar.ptr) if dt_scalar is not None else None
+        check(self._fn("mgpu_edge_join")(self.handle, ptrs))
 
     def exchange(self, sides, names):
         self.finish(self.start(sides, names))

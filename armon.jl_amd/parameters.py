@@ -219,7 +219,7 @@ class ArmonParameters:
 
     # ref src/parameters.jl:766-778 — backend specific options (like ext/ArmonKokkos.jl:83-87)
     def _init_backend(self, device_id=None, use_fused_sweep=True, exact_arithmetic=False, stream=None,
-                      placement_tries=32, stream_ordered_halo=True, ctx=None, native_halo=True, overlap_halo=True,
+                      placement_tries=32, stream_ordered_halo=True, ctx=None, native_halo=True, overlap_halo=True, edge_stream=True,
                       placement_min_bytes=256 << 20, placement_rounds=3, **options):
         """``device_id``: GPU ordinal (default LOCAL_RANK or 0). ``use_fused_sweep``: run each sweep as
         the fused HIP kernel instead of the 5 staged kernels. ``exact_arithmetic=True``: IEEE division/sqrt
@@ -236,6 +236,7 @@ class ArmonParameters:
         self._ctx = ctx         # an existing armon_ctx to adopt (a tile context owned by an armon_mgpu group)
         self.native_halo = bool(native_halo)    # N>1 over RCCL: halo exchange / dt all-reduce by the library itself
         self.overlap_halo = bool(overlap_halo)  # sweep the interior while the halos travel
+        self.edge_stream = bool(edge_stream)    # native groups: unpack + boundary strips on the transfer stream, concurrent with the interior
         self._device = None     # created on first use, so that configuration errors need no GPU
         # per-step dumps / comparisons need the intermediate states: only the staged path has them
         self.use_fused_sweep = bool(use_fused_sweep) and not self.compare

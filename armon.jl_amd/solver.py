@@ -488,13 +488,20 @@ def sweep_lag(params):
 
 
 def fused_sweep(params, grid, axis, dt, dx, emit_p=False, emit_c=False, emit_dt=False,
-                out_range=None, dt_accumulate=False, swap=True):
+                out_range=None, dt_accumulate=False, swap=True, ctx=None, dt_out=None):
     """One directional sweep as a single kernel launch (armon_hip_sweep). The halo cells of process
     boundaries must already hold the neighbour's (ρ,u,v,E). ``emit_dt``: also reduce the CFL time step
-    of the resulting state into ``grid.dt_scalar`` (device)."""
+    of the resulting state into ``grid.dt_scalar`` (device) — or into ``dt_out``. ``ctx``: another context of the same
+    device to launch on (the tile's edge stream, multi_gpu.hip); such launches are not seen by the kernel callbacks,
+    whose events live on the compute stream."""
     d = sweep_desc(params, grid, axis, dt, dx, emit_p, emit_c, emit_dt, out_range, dt_accumulate)
-    with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
-        check(params.fn("sweep")(params.device.ctx, C.byref(d)))
+    if emit_dt and dt_out is not None:
+        d.dt_cfl_out = dt_out
+    if ctx is not None:
+        check(params.fn("sweep")(ctx, C.byref(d)))
+    else:
+        with _k(params, "sweep_x" if axis == Axis.X else "sweep_y"):
+            check(params.fn("sweep")(params.device.ctx, C.byref(d)))
     if swap:
         grid.swap_state()
 
@@ -555,11 +562,21 @@ def fused_sweep_overlapped(params, grid, axis, dt, dx, **emit):
         handle = comm.start(sides_along(axis), STATE_VARS)
     lo, hi = (lag if lo_remote else 0), (n - lag if hi_remote else n)
     fused_sweep(params, grid, axis, dt, dx, out_range=(lo, hi), swap=False, **emit)
-    comm.finish(handle)
-    if lo_remote:
-        fused_sweep(params, grid, axis, dt, dx, out_range=(0, lag), swap=False, dt_accumulate=True, **emit)
-    if hi_remote:
-        fused_sweep(params, grid, axis, dt, dx, out_range=(n - lag, n), swap=False, dt_accumulate=True, **emit)
+    if getattr(comm, "edge_ctx", None) and getattr(params, "edge_stream", True):
+        # the library's group: unpack and strips on the tile's transfer stream, in the shadow of the interior
+        comm.finish_edge(handle)
+        sz = np.dtype(params.data_type).itemsize
+        for k, (remote, rng) in enumerate(((lo_remote, (0, lag)), (hi_remote, (n - lag, n)))):
+            if remote:
+                fused_sweep(params, grid, axis, dt, dx, out_range=rng, swap=False, ctx=comm.edge_ctx,
+                            dt_out=comm.edge_dt + k * sz, **emit)
+        comm.edge_join(grid.dt_scalar if emit.get("emit_dt") else None)
+    else:
+        comm.finish(handle)
+        if lo_remote:
+            fused_sweep(params, grid, axis, dt, dx, out_range=(0, lag), swap=False, dt_accumulate=True, **emit)
+        if hi_remote:
+            fused_sweep(params, grid, axis, dt, dx, out_range=(n - lag, n), swap=False, dt_accumulate=True, **emit)
     grid.swap_state()
 
 

@@ -407,6 +407,24 @@ ARMON_API int armon_hip_halo_exchange_start_f32(armon_mgpu*, int axis, const arm
 ARMON_API int armon_hip_halo_exchange_finish_f32(armon_mgpu*, int axis, const armon_halo_desc* tiles);
 ARMON_API int armon_hip_halo_exchange_f32(armon_mgpu*, int axis, const armon_halo_desc* tiles);
 
+/* Edge stream. What follows the receive of a sweep's faces — the unpack and the LAG-wide strips next to the remote
+ * sides — reads the same input state as the interior sweep and writes cells the interior does not, so it can run on the
+ * tile's TRANSFER stream while the interior runs on the compute stream, instead of in a chain of small launches after
+ * it (the interior reads no ghost cell and never writes the strips' cells):
+ *     armon_hip_halo_exchange_start -> armon_hip_sweep(ctx, interior) -> armon_hip_halo_exchange_finish_edge
+ *     -> armon_hip_sweep(edge_ctx, strip) per remote side, dt_cfl_out = edge_dt + side index, dt_accumulate = 0
+ *     -> armon_hip_mgpu_edge_join(group, dt_dev or NULL)
+ * _edge_ctx: the tile's context on its transfer stream (owned by the group). _edge_dt: 2 device scalars of the run's
+ * precision for the strips' CFL steps. _edge_join: every compute stream waits for its tile's edge work; with dt_dev,
+ * dt_dev[k] = min(dt_dev[k], the tile's two edge scalars) on the compute stream, and the edge scalars are reset.
+ * Replaces the interconnect-free part of ref src/halo_exchange.jl:256-283 (finish_exchange + the boundary blocks). */
+ARMON_API armon_ctx* armon_hip_mgpu_edge_ctx(armon_mgpu* group, int local_tile);
+ARMON_API void* armon_hip_mgpu_edge_dt(armon_mgpu* group, int local_tile);
+ARMON_API int armon_hip_halo_exchange_finish_edge(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+ARMON_API int armon_hip_halo_exchange_finish_edge_f32(armon_mgpu*, int axis, const armon_halo_desc* tiles);
+ARMON_API int armon_hip_mgpu_edge_join(armon_mgpu*, double* const* dt_dev);
+ARMON_API int armon_hip_mgpu_edge_join_f32(armon_mgpu*, float* const* dt_dev);
+
 /* Global minimum of one device scalar per local tile (dt_cfl_out of the fused sweep / armon_hip_dtCFL_async), in
  * place, ordered on the compute streams: afterwards every dt_dev[k] holds the minimum over ALL tiles of the group.
  * The reference consumes it one cycle later (ref src/solver_state.jl:145-166): nothing is waited for on the host. */

@@ -118,10 +118,12 @@ def test_native_tile_group_equals_one_block(P, N, test, opts, fused):
 
 
 def test_native_tile_group_tuned_f32_and_no_overlap():
-    """The other knobs of the same path: tuned arithmetic, Float32 (the _f32 entry points), overlap switched off."""
+    """The other knobs of the same path: tuned arithmetic, Float32 (the _f32 entry points), overlap switched off, the
+    boundary strips on the compute stream instead of the edge stream (the default everywhere else in this file)."""
     import armon_amd
     from armon_amd.multi_tile import TileGroup
-    for o in (dict(), dict(data_type="float32", exact_arithmetic=True), dict(overlap_halo=False, exact_arithmetic=True)):
+    for o in (dict(), dict(data_type="float32", exact_arithmetic=True), dict(overlap_halo=False, exact_arithmetic=True),
+              dict(edge_stream=False), dict(edge_stream=False, data_type="float32")):     # strips after the interior, in order
         kw = dict(test="Sod_circ", N=(96, 80), maxcycle=10, silent=5, **o)
         ref = armon_amd.armon(armon_amd.ArmonParameters(return_data=True, **kw))
         host = ref.data.device_to_host(("rho", "u", "v", "E", "p"))
