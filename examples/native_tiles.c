@@ -1,6 +1,7 @@
 /* native_tiles.c — the tile-decomposed hot path driven from plain C through include/armon_hip.h only: a px x py grid
  * of tiles in ONE process (armon_hip_mgpu_init; every tile on device 0 unless device ids are given), per sweep
- *   armon_hip_halo_exchange_start -> interior of the fused sweep -> armon_hip_halo_exchange_finish -> boundary strips,
+ *   armon_hip_halo_exchange_start -> interior of the fused sweep on the compute stream, while on the tile's transfer
+ *   stream: armon_hip_halo_exchange_finish_edge -> boundary strips (armon_hip_mgpu_edge_ctx) -> armon_hip_mgpu_edge_join,
  * the dt/CFL minimum reduced over the tiles on the device (armon_hip_dt_allreduce) and read back one cycle late — the
  * reference's cycle (ref src/solver.jl:288-320) with its MPI exchange (ref src/halo_exchange.jl:229-354) and
  * MPI_Iallreduce (ref src/solver_state.jl:89-111) replaced by the library's own entry points. No host synchronisation
@@ -23,7 +24,8 @@
 enum { G = 4, LAG = 4, MAX_TILES = 64 };
 
 typedef struct {
-    armon_ctx* ctx;
+    armon_ctx *ctx, *edge;           /* compute stream; transfer ("edge") stream */
+    double* edge_dt;                 /* 2 device scalars for the strips' CFL steps */
     int64_t nx, ny, ox, oy;          /* real cells and 0-based global position of the tile */
     int nb[4];                       /* neighbour rank per ARMON_SIDE_*, -1 = physical boundary */
     double* f[20];                   /* 16 BlockData vectors + 4 ping-pong partners */
@@ -31,8 +33,9 @@ typedef struct {
     double* dt_dev;
 } tile;
 
-/* one fused sweep of a sub-range [lo, hi) of the sweep axis (hi == 0: the whole tile) */
-static int sweep(tile* t, int axis, double dt, double dx, int64_t lo, int64_t hi, int emit_dt, int accumulate)
+/* one fused sweep of a sub-range [lo, hi) of the sweep axis (hi == 0: the whole tile), launched on `ctx`; dt_out: where
+ * the CFL step of the cells it produced goes (NULL: not wanted) */
+static int sweep(tile* t, armon_ctx* ctx, int axis, double dt, double dx, int64_t lo, int64_t hi, double* dt_out)
 {
     armon_sweep_desc d;
     memset(&d, 0, sizeof d);
@@ -46,8 +49,8 @@ static int sweep(tile* t, int axis, double dt, double dx, int64_t lo, int64_t hi
     d.rho_in = t->s[0]; d.u_in = t->s[1]; d.v_in = t->s[2]; d.E_in = t->s[3];
     d.rho_out = t->a[0]; d.u_out = t->a[1]; d.v_out = t->a[2]; d.E_out = t->a[3];
     d.out_lo = lo; d.out_hi = hi;
-    if (emit_dt) { d.dt_cfl_out = t->dt_dev; d.cfl_dx = d.cfl_dy = dx; d.dt_accumulate = accumulate; }
-    return armon_hip_sweep(t->ctx, &d);
+    if (dt_out) { d.dt_cfl_out = dt_out; d.cfl_dx = d.cfl_dy = dx; }
+    return armon_hip_sweep(ctx, &d);
 }
 
 int main(int argc, char** argv)
@@ -68,6 +71,8 @@ int main(int argc, char** argv)
         tile* t = &T[r];
         int coords[2];
         t->ctx = armon_hip_mgpu_ctx(group, r);
+        t->edge = armon_hip_mgpu_edge_ctx(group, r);
+        t->edge_dt = (double*)armon_hip_mgpu_edge_dt(group, r);
         CHECK(armon_hip_mgpu_tile_info(group, r, NULL, coords, t->nb));
         /* partition of ref src/parameters.jl:673-697: N / P cells, the remainder on the last tile of the axis */
         t->nx = n / px + (coords[0] == px - 1 ? n % px : 0);
@@ -117,17 +122,21 @@ int main(int argc, char** argv)
                 const int s_lo = axis == ARMON_AXIS_X ? ARMON_SIDE_LEFT : ARMON_SIDE_BOTTOM;
                 const int64_t na = axis == ARMON_AXIS_X ? t->nx : t->ny;
                 const int64_t lo = t->nb[s_lo] >= 0 ? LAG : 0, hi = t->nb[s_lo + 1] >= 0 ? na - LAG : na;
-                CHECK(sweep(t, axis, dt, dx, lo, (lo == 0 && hi == na) ? 0 : hi, last, 0));
+                CHECK(sweep(t, t->ctx, axis, dt, dx, lo, (lo == 0 && hi == na) ? 0 : hi, last ? t->dt_dev : NULL));
             }
-            CHECK(armon_hip_halo_exchange_finish(group, axis, halo));
-            for (int r = 0; r < nt; r++) {                     /* the LAG-wide strips next to the remote sides */
+            /* on the transfer streams, concurrent with the interiors: unpack, then the LAG-wide strips next to the remote
+             * sides (they read the same input state and write cells the interior does not) */
+            CHECK(armon_hip_halo_exchange_finish_edge(group, axis, halo));
+            for (int r = 0; r < nt; r++) {
                 tile* t = &T[r];
                 const int s_lo = axis == ARMON_AXIS_X ? ARMON_SIDE_LEFT : ARMON_SIDE_BOTTOM;
                 const int64_t na = axis == ARMON_AXIS_X ? t->nx : t->ny;
-                if (t->nb[s_lo] >= 0) CHECK(sweep(t, axis, dt, dx, 0, LAG, last, 1));
-                if (t->nb[s_lo + 1] >= 0) CHECK(sweep(t, axis, dt, dx, na - LAG, na, last, 1));
+                if (t->nb[s_lo] >= 0) CHECK(sweep(t, t->edge, axis, dt, dx, 0, LAG, last ? t->edge_dt : NULL));
+                if (t->nb[s_lo + 1] >= 0) CHECK(sweep(t, t->edge, axis, dt, dx, na - LAG, na, last ? t->edge_dt + 1 : NULL));
                 for (int k = 0; k < 4; k++) { double* tmp = t->s[k]; t->s[k] = t->a[k]; t->a[k] = tmp; }
             }
+            /* compute streams wait for their tile's edge work; after the last sweep the strips' CFL steps are folded in */
+            CHECK(armon_hip_mgpu_edge_join(group, last ? dt_ptrs : NULL));
         }
         /* global minimum on the device, read back one cycle late from tile 0 (ref src/solver_state.jl:145-166) */
         CHECK(armon_hip_dt_allreduce(group, dt_ptrs));
