@@ -368,5 +368,15 @@ halo_exchange_finish!(g::TileGroup, axis, tiles::Vector{HaloDesc}, ::Type{T} = F
     check(ccall(fn(:armon_hip_halo_exchange_finish, T), Cint, (Ptr{Cvoid}, Cint, Ptr{HaloDesc}), g.handle, Int(axis) - 1, tiles))
 dt_allreduce!(g::TileGroup, dt_dev::Vector{Ptr{T}}) where T =
     check(ccall(fn(:armon_hip_dt_allreduce, T), Cint, (Ptr{Cvoid}, Ptr{Ptr{T}}), g.handle, dt_dev))
+# edge stream: unpack + the LAG-wide boundary strips on the tile's transfer stream, concurrent with the interior sweep
+# (launch the strips with `fused_sweep!` on `edge_context(g, k)`, `dt_cfl_out = edge_dt(g, k, T) + side index`)
+edge_context(g::TileGroup, k) = ccall(fn(:armon_hip_mgpu_edge_ctx), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), g.handle, k)
+edge_dt(g::TileGroup, k, ::Type{T} = Float64) where T =
+    Ptr{T}(ccall(fn(:armon_hip_mgpu_edge_dt), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), g.handle, k))
+halo_exchange_finish_edge!(g::TileGroup, axis, tiles::Vector{HaloDesc}, ::Type{T} = Float64) where T =
+    check(ccall(fn(:armon_hip_halo_exchange_finish_edge, T), Cint, (Ptr{Cvoid}, Cint, Ptr{HaloDesc}), g.handle, Int(axis) - 1, tiles))
+edge_join!(g::TileGroup, dt_dev::Vector{Ptr{T}}) where T =          # after the last sweep of a cycle: folds the strips' dt in
+    check(ccall(fn(:armon_hip_mgpu_edge_join, T), Cint, (Ptr{Cvoid}, Ptr{Ptr{T}}), g.handle, dt_dev))
+edge_join!(g::TileGroup) = check(ccall(fn(:armon_hip_mgpu_edge_join), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}), g.handle, C_NULL))
 
 end # module
