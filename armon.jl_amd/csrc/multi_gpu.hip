@@ -132,6 +132,10 @@ struct armon_mgpu {
     // in-process reductions: gather on tiles[0]'s device
     double* red_buf = nullptr;                   // [n_tiles] (doubles; fp32 runs use the first half of each slot)
     hipEvent_t e_red_done = nullptr;
+    // test aid (armon_hip_mgpu_set_chaos): pseudo-random busy-wait kernels in front of the group's own stream operations,
+    // to shake the event ordering under timings one GPU never produces by itself
+    unsigned chaos_us = 0;
+    uint64_t chaos_rng = 0x9E3779B97F4A7C15ull;
     // RCCL
     ncclComm_t comm_halo = nullptr, comm_red = nullptr;
     double* red_scratch = nullptr;               // device, [16]: host-value all-reduces
@@ -139,6 +143,24 @@ struct armon_mgpu {
 };
 
 namespace {
+
+__global__ void k_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();               // constant-rate counter (100 MHz)
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+// chaos mode: with probability 1/2, hold `stream` for up to chaos_us microseconds
+void chaos(armon_mgpu* g, hipStream_t stream)
+{
+    if (!g->chaos_us) return;
+    uint64_t& r = g->chaos_rng;
+    r ^= r << 13; r ^= r >> 7; r ^= r << 17;
+    if (r & 1) return;
+    const unsigned long long us = 1 + (r >> 8) % g->chaos_us;
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, stream, us * 100ull);
+    (void)hipGetLastError();
+}
 
 // ref MPI.Cart_coords / Cart_shift on a non-periodic px × py grid, last dimension fastest (src/parameters.jl:441-447)
 void set_topology(tile_t& t, int rank, int px, int py)
@@ -254,6 +276,7 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
                 tile_t& n = g->tiles[t.nb[s]];
                 if (n.rec_recv[opposite(s)]) ARMON_HIP_TRY(hipStreamWaitEvent(t.ctx->stream, n.e_recv[opposite(s)], 0));
             }
+            chaos(g, t.ctx->stream);
             rc = pack<T>(t.ctx, border, d[k].nghost, face, static_cast<T*>(t.send[s]), d[k].nvars,
                          reinterpret_cast<const T* const*>(d[k].vars));
             if (rc != ARMON_OK) return rc;
@@ -268,6 +291,8 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
         for (int s = s0; s < s0 + 2; s++) any = any || t.inflight[s] != 0;
         if (!any) continue;
         ARMON_HIP_TRY(hipSetDevice(t.device));
+        chaos(g, t.xfer);                         // late faces
+        chaos(g, t.ctx->stream);                  // or a late interior: the edge work then runs ahead of it
         if (g->rccl) {
             for (int s = s0; s < s0 + 2; s++) {
                 if (!t.inflight[s]) continue;
@@ -328,6 +353,7 @@ int exchange_finish(armon_mgpu* g, int axis, const armon_halo_desc* d, bool on_e
             ARMON_HIP_TRY(hipSetDevice(t.device));
             // on the transfer stream the unpack simply follows the receive; on the compute stream it waits for it
             armon_ctx* c = on_edge ? t.edge : t.ctx;
+            chaos(g, c->stream);
             if (!on_edge) ARMON_HIP_TRY(hipStreamWaitEvent(c->stream, t.e_recv[s], 0));
             rc = unpack<T>(c, ghost, d[k].nghost, face, static_cast<const T*>(t.recv[s]), d[k].nvars,
                            reinterpret_cast<T* const*>(d[k].vars));
@@ -373,6 +399,7 @@ int edge_join(armon_mgpu* g, T* const* dt_dev)
     for (size_t k = 0; k < g->tiles.size(); k++) {
         tile_t& t = g->tiles[k];
         ARMON_HIP_TRY(hipSetDevice(t.device));
+        chaos(g, t.xfer);                         // strips that finish long after the interior
         ARMON_HIP_TRY(hipEventRecord(t.e_edge, t.xfer));
         ARMON_HIP_TRY(hipStreamWaitEvent(t.ctx->stream, t.e_edge, 0));
         if (dt_dev) {
@@ -417,6 +444,8 @@ int dt_allreduce(armon_mgpu* g, T* const* dt_dev)
     }
     if (nt == 1) return ARMON_OK;
     tile_t& root = g->tiles[0];
+    for (size_t k = 0; k < nt; k++) chaos(g, g->tiles[k].ctx->stream);
+    chaos(g, root.xfer);
     bool one_device = nt <= (size_t)kMaxDirect;
     for (size_t k = 0; k < nt; k++) one_device = one_device && g->tiles[k].device == root.device;
     if (one_device) {
@@ -636,6 +665,15 @@ int armon_hip_mgpu_destroy(armon_mgpu* g)
     if (g->red_scratch) (void)hipFree(g->red_scratch);
     if (g->red_scratch_host) (void)hipHostFree(g->red_scratch_host);
     delete g;
+    return ARMON_OK;
+}
+
+int armon_hip_mgpu_set_chaos(armon_mgpu* g, unsigned max_delay_us, uint64_t seed)
+{
+    ARMON_REQUIRE(g, "NULL argument");
+    ARMON_REQUIRE(max_delay_us <= 20000, "delays above 20 ms are not a test any more");
+    g->chaos_us = max_delay_us;
+    g->chaos_rng = seed ? seed : 0x9E3779B97F4A7C15ull;
     return ARMON_OK;
 }
 

@@ -91,6 +91,10 @@ class TileGroup:
         except Exception:
             pass
 
+    def set_chaos(self, max_delay_us, seed=0):
+        """Test aid: random busy-wait kernels in front of the group's stream operations (armon_hip_mgpu_set_chaos)."""
+        check(self._L.armon_hip_mgpu_set_chaos(self.handle, int(max_delay_us), int(seed)))
+
     def _fn(self, name):
         return getattr(self._L, "armon_hip_" + name + self.root.suffix)
 

@@ -383,6 +383,10 @@ ARMON_API int armon_hip_mgpu_unique_id(void* id);
 ARMON_API int armon_hip_mgpu_init_rank(int px, int py, int rank, int device_id, void* stream, const void* id,
                                        armon_mgpu** group);
 ARMON_API int armon_hip_mgpu_destroy(armon_mgpu* group);
+/* Test aid: from now on, with probability 1/2 each, the group's stream operations (packs, transfers, unpacks, the edge
+ * join, the dt reduction) are preceded by a busy-wait kernel of up to max_delay_us on their stream — timings a single
+ * GPU never produces by itself; results must not change. 0 switches it off. seed 0 = default sequence. */
+ARMON_API int armon_hip_mgpu_set_chaos(armon_mgpu* group, unsigned max_delay_us, uint64_t seed);
 ARMON_API int armon_hip_mgpu_n_local(armon_mgpu* group);                       /* tiles owned by this process */
 ARMON_API armon_ctx* armon_hip_mgpu_ctx(armon_mgpu* group, int local_tile);    /* that tile's context (owned by the group) */
 /* rank, cartesian coords and the neighbour rank per ARMON_SIDE_* (-1 = physical boundary, MPI.PROC_NULL) */

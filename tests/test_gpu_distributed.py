@@ -138,6 +138,36 @@ def test_native_tile_group_tuned_f32_and_no_overlap():
             group.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("P,N,test,opts", [
+    ((2, 2), (96, 80), "Sod_circ", dict(maxcycle=12)),
+    ((4, 2), (160, 96), "Bizarrium", dict(maxcycle=10)),                       # BASELINE config 5's layout
+    ((3, 3), (93, 99), "Sedov", dict(maxcycle=10, axis_splitting="Strang")),    # a tile with 4 neighbours, X-last cycles
+    ((3, 1), (70, 48), "Sod", dict(maxcycle=10, edge_stream=False)),            # the in-order form of the strips
+])
+def test_native_tile_group_survives_injected_delays(P, N, test, opts, seed):
+    """The event ordering of the library's exchange (pack → transfer → unpack → strips on the edge stream → join → next
+    pack; the dt reduction) under timings one GPU never produces by itself: armon_hip_mgpu_set_chaos puts busy-wait
+    kernels of up to 300 µs — longer than any kernel of these small tiles — in front of the group's stream operations
+    at random. A missing dependency would show as stale ghost cells; the result must stay bit-identical."""
+    import armon_amd
+    from armon_amd.multi_tile import TileGroup
+    o = dict(opts)
+    ref = armon_amd.armon(armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True,
+                                                    **{k: v for k, v in o.items() if k != "edge_stream"}))
+    host = ref.data.device_to_host(("rho", "u", "v", "E", "p"))
+    group = TileGroup(P, test=test, N=N, silent=5, **o)
+    try:
+        group.set_chaos(300, seed)
+        stats = group.run()
+        assert stats.cycles == ref.cycles and stats.last_dt == ref.last_dt and stats.final_time == ref.final_time
+        got = group.gather()
+        for k in ("rho", "u", "v", "E", "p"):
+            assert np.array_equal(got[k], ref.data.real_view(host[k])), k
+    finally:
+        group.close()
+
+
 def test_native_halo_exchange_moves_index_encoded_faces():
     """The exchange alone, with the index-encoding design of ref test/mpi.jl:272-360: every cell of every variable
     holds var·1e7 + its GLOBAL linear index; after both axes each remote ghost cell holds the index of the cell it
