@@ -158,7 +158,9 @@ class BlockGrid:
         search may stop after 12 draws once two of them lie within 1 % of the best and 7 % under the worst; transient
         memory = the 8 ``spare`` vectors only (17 GB at 16384²). The pool is deliberately small: among 12-16 vectors
         allocated one after the other about half of the random draws land on the fast level, among 32 one in twenty
-        (profiles/r02_placement_pool_sizes.txt) — up to ``placement_tries`` = 32 draws make a miss unlikely.
+        (profiles/r02_placement_pool_sizes.txt). A pool is either slow for EVERY assignment or fast for most of them
+        (profiles/r02_placement_what_it_is_not.txt), so a round is short — ``placement_tries`` = 16 draws — and a round
+        that found nothing is followed by a fresh batch of spares, up to ``placement_rounds`` = 5 times.
         ``keep_state=True``: ``armon_hip_tune_placement`` moves a LIVE state around (4 more vectors park it meanwhile). ~20 ms per try, outside any timed region.
         Returns the report also stored in ``self.placement``."""
         params, dev = self.params, self.params.device
