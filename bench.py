@@ -237,8 +237,9 @@ def main():
             could_order = torch_comm.stream_ordered
             ref = probe(torch_comm, False)
             halo_mode, chosen = None, None
-            candidates = ([("native (armon_hip_halo_exchange over RCCL send/recv on a transfer stream, "
-                            "armon_hip_dt_allreduce; device-ordered)", native_comm, True)] if native_comm else [])
+            candidates = ([("native (armon_hip_halo_exchange over RCCL send/recv on a transfer stream, unpack and boundary "
+                            "strips on that stream too, armon_hip_dt_allreduce; device-ordered)", native_comm, True)]
+                          if native_comm else [])
             if could_order:
                 candidates.append(("torch.distributed RCCL, stream-ordered", torch_comm, True))
             failed = []
