@@ -265,7 +265,10 @@ function fused_state(p::HP{T}, grid::BlockGrid) where T
 end
 
 "One directional sweep of one block as ONE launch (armon_hip_sweep), then exchange the roles of the two state sets."
-function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}; emit_p::Bool, emit_dt::Bool) where T
+function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}; emit_p::Bool, emit_dt::Bool,
+                      out::NTuple{2, Int} = (0, 0),            # cells [out[1], out[2]) of the sweep axis; (0, 0) = all
+                      ctx::Ptr{Cvoid} = p.device.ctx,          # or the tile's edge context (transfer stream)
+                      dt_out::Ptr{T} = pointer(fs.dt_dev), swap::Bool = true) where T
     d = block_device_data(blk); alt = fs.alt[blk]
     nx, ny = real_block_size(blk.size)
     lo, hi = first_side(state.axis), last_side(state.axis)
@@ -279,20 +282,69 @@ function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::Fus
         pointer(d.ρ), pointer(d.u), pointer(d.v), pointer(d.E),
         pointer(alt[1]), pointer(alt[2]), pointer(alt[3]), pointer(alt[4]),
         emit_p ? pointer(d.p) : Ptr{T}(C_NULL), Ptr{T}(C_NULL),
-        emit_dt ? pointer(fs.dt_dev) : Ptr{T}(C_NULL), Δ[1], Δ[2], 0, 0, 0, 0))
-    GC.@preserve d alt check(ccall(fn(:armon_hip_sweep, T), Cint, (Ptr{Cvoid}, Ptr{SweepDesc{T}}), p.device.ctx, desc))
-    # ping-pong: the fresh state lives in `alt`; BlockData is immutable but HIPVector is ours — swap the allocations
-    for (v, a) in zip((d.ρ, d.u, d.v, d.E), alt)
+        emit_dt ? dt_out : Ptr{T}(C_NULL), Δ[1], Δ[2], out[1], out[2], 0, 0))
+    GC.@preserve d alt check(ccall(fn(:armon_hip_sweep, T), Cint, (Ptr{Cvoid}, Ptr{SweepDesc{T}}), ctx, desc))
+    swap && swap_state!(blk, fs)
+end
+
+"ping-pong: the fresh state lives in `alt`; BlockData is immutable but HIPVector is ours — swap the allocations"
+function swap_state!(blk::LocalTaskBlock, fs::FusedState)
+    d = block_device_data(blk)
+    for (v, a) in zip((d.ρ, d.u, d.v, d.E), fs.alt[blk])
         v.ptr, a.ptr = a.ptr, v.ptr
     end
 end
 
+# Under MPI the fused sweeps exchange their halos through the library's RCCL group (one process per GPU, INTEGRATION §3)
+# instead of the reference's MPI requests: faces of (ρ,u,v,E) only, posted before the interior of the sweep, unpacked on
+# the transfer stream where the LAG-wide boundary strips follow, nothing waited for on the host
+# (replaces ref src/halo_exchange.jl:229-354 for this path).
+const RANK_GROUPS = IdDict{Any, Any}()
+function rank_group(p::HP)
+    get!(RANK_GROUPS, p) do
+        px, py = p.proc_dims
+        me = p.cart_coords[1] * py + p.cart_coords[2]      # rank in p.cart_comm: cartesian ranks are row-major (MPI 7.5)
+        id = me == 0 ? unique_id() : zeros(UInt8, 256)
+        MPI.Bcast!(id, 0, p.cart_comm)
+        stream = ccall(fn(:armon_hip_stream), Ptr{Cvoid}, (Ptr{Cvoid},), p.device.ctx)
+        TileGroup(px, py, me, p.device.device_id, id; stream)    # adopts the stream the sweeps are already enqueued on
+    end
+end
+
+sweep_lag(state::SolverState) = 2 + Int(scheme_tag(state.riemann_scheme)) + Int(projection_tag(state.projection_scheme))
+
+function fused_sweep_mpi!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}; emit_p::Bool, emit_dt::Bool) where T
+    lo_r = has_neighbour(p, first_side(state.axis)); hi_r = has_neighbour(p, last_side(state.axis))
+    (lo_r || hi_r) || return fused_sweep!(p, state, blk, fs; emit_p, emit_dt)
+    g = rank_group(p)
+    d = block_device_data(blk)
+    nx, ny = real_block_size(blk.size)
+    n = state.axis == Axis.X ? nx : ny
+    lag = sweep_lag(state)
+    halo = [HaloDesc(nx, ny, ghosts(blk.size), (d.ρ, d.u, d.v, d.E))]
+    GC.@preserve d begin
+        halo_exchange_start!(g, state.axis, halo, T)
+        if n < 2lag + 1                                    # no interior to hide the transfer behind
+            halo_exchange_finish!(g, state.axis, halo, T)
+            return fused_sweep!(p, state, blk, fs; emit_p, emit_dt)
+        end
+        fused_sweep!(p, state, blk, fs; emit_p, emit_dt, out = (lo_r ? lag : 0, hi_r ? n - lag : n), swap = false)
+        halo_exchange_finish_edge!(g, state.axis, halo, T)
+        edge = edge_context(g, 0); e_dt = edge_dt(g, 0, T)
+        lo_r && fused_sweep!(p, state, blk, fs; emit_p, emit_dt, out = (0, lag), ctx = edge, dt_out = e_dt, swap = false)
+        hi_r && fused_sweep!(p, state, blk, fs; emit_p, emit_dt, out = (n - lag, n), ctx = edge, dt_out = e_dt + sizeof(T), swap = false)
+        emit_dt ? edge_join!(g, [pointer(fs.dt_dev)]) : edge_join!(g)
+    end
+    swap_state!(blk, fs)
+end
+
 function solver_cycle(p::HP{T}, grid::BlockGrid) where T
-    # per-step dumps/comparisons need the intermediate arrays of the staged kernels; MPI runs keep the reference's
-    # exchange between the staged kernels (the fused multi-GPU path is armon_hip_mgpu_* / halo_exchange, INTEGRATION §3)
-    if !p.backend_options.fused_sweep || p.compare || p.use_MPI
+    # per-step dumps/comparisons need the intermediate arrays of the staged kernels (then MPI runs keep the reference's
+    # exchange between them, on gpu_aware buffers); otherwise MPI runs take the library's RCCL group, see above
+    if !p.backend_options.fused_sweep || p.compare
         return invoke(solver_cycle, Tuple{ArmonParameters, BlockGrid}, p, grid)
     end
+    mpi = p.use_MPI && p.proc_size > 1
     state = first_state(grid)
     gdt = state.global_dt
     fs = fused_state(p, grid)
@@ -308,10 +360,13 @@ function solver_cycle(p::HP{T}, grid::BlockGrid) where T
         update_solver_state!(p, state, axis, dt_factor)
         last = k == length(sweeps)
         for blk in all_blocks(grid)                       # one block per GPU (use_cache_blocking=false)
-            fused_sweep!(p, state, blk, fs; emit_p = last && will_end, emit_dt = last && !p.cst_dt)
+            (mpi ? fused_sweep_mpi! : fused_sweep!)(p, state, blk, fs; emit_p = last && will_end, emit_dt = last && !p.cst_dt)
         end
     end
     p.cst_dt && return false
+    # global minimum over the tiles, on the device (replaces the MPI_Iallreduce of ref src/solver_state.jl:89-111; the
+    # reference's own all-reduce in update_dt! then sees the same value on every rank)
+    mpi && dt_allreduce!(rank_group(p), [pointer(fs.dt_dev)])
     # post the read-back of the CFL step this cycle's last sweep reduced (the state the NEXT cycle starts from) …
     slot = gdt.cycle & 1
     check(ccall(fn(:armon_hip_memcpy_async), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint),
@@ -354,10 +409,10 @@ function TileGroup(px, py, device_ids::Vector{Cint})
     finalizer(x -> ccall(fn(:armon_hip_mgpu_destroy), Cint, (Ptr{Cvoid},), x.handle), TileGroup(g[], px, py))
 end
 "One process per GPU under MPI: `id` = the bytes of armon_hip_mgpu_unique_id from rank 0 after MPI.Bcast!."
-function TileGroup(px, py, rank, device_id, id::Vector{UInt8})
+function TileGroup(px, py, rank, device_id, id::Vector{UInt8}; stream::Ptr{Cvoid} = C_NULL)
     g = Ref{Ptr{Cvoid}}()
     check(ccall(fn(:armon_hip_mgpu_init_rank), Cint, (Cint, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
-        px, py, rank, device_id, C_NULL, id, g))
+        px, py, rank, device_id, stream, id, g))
     finalizer(x -> ccall(fn(:armon_hip_mgpu_destroy), Cint, (Ptr{Cvoid},), x.handle), TileGroup(g[], px, py))
 end
 unique_id() = (id = zeros(UInt8, 256); check(ccall(fn(:armon_hip_mgpu_unique_id), Cint, (Ptr{Cvoid},), id)); id)
