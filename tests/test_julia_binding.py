@@ -177,3 +177,79 @@ def test_device_array_type_and_fused_override_are_what_the_reference_needs():
                    "armon_hip_event_sync", "invoke(solver_cycle"):
         assert needle in body, needle
     assert "v.ptr, a.ptr = a.ptr, v.ptr" in CODE        # ping-pong swap of the allocations behind BlockData's vectors
+
+
+def _strip_julia(src):
+    """Julia source without comments, string / char literals and docstrings (contents replaced by blanks)."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith('"""', i):
+            j = src.index('"""', i + 3) + 3
+            out.append(" " * (j - i))
+            i = j
+        elif c == '"':
+            j = i + 1
+            while src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            out.append('""' + " " * (j - i - 1))
+            i = j + 1
+        elif c == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")):
+            j = i + (3 if src[i + 2] == "'" else 4)
+            out.append(" " * (j - i))
+            i = j
+        elif c == "#":
+            j = src.find("\n", i)
+            j = n if j < 0 else j
+            out.append(" " * (j - i))
+            i = j
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def test_julia_file_is_structurally_sound():
+    """The file cannot be executed here: at least every block opener has its `end`, brackets pair up, and the functions
+    the overrides call exist under the names they are called by."""
+    src = _strip_julia(JL)
+    # brackets
+    stack = []
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for k, ch in enumerate(src):
+        if ch in "([{":
+            stack.append((ch, k))
+        elif ch in ")]}":
+            assert stack and stack[-1][0] == pairs[ch], f"unbalanced {ch!r} at line {src.count(chr(10), 0, k) + 1}"
+            stack.pop()
+    assert not stack, f"unclosed {stack[-1][0]!r} at line {src.count(chr(10), 0, stack[-1][1]) + 1}"
+    # blocks: openers at the start of a statement or after `=`/`(`/`,` (begin, do, let, try), `end` as a word outside []
+    depth_sq, opens, ends = 0, 0, 0
+    tokens = re.finditer(r"[\[\]]|\b(function|if|for|while|begin|do|struct|module|let|try|macro|quote|end)\b", src)
+    prev_word_at = {}
+    for m in tokens:
+        t = m.group(0)
+        if t == "[":
+            depth_sq += 1
+        elif t == "]":
+            depth_sq -= 1
+        elif t == "end":
+            if depth_sq == 0:
+                ends += 1
+        elif t == "struct":
+            opens += 1          # `mutable struct` is one opener (mutable is not in the list)
+        elif t in ("if", "for", "while"):
+            # a block opener only at the start of a statement; inside (...) or [...] it is a generator / ternary-free filter
+            line_start = src.rfind("\n", 0, m.start()) + 1
+            before = src[line_start:m.start()]
+            if before.strip() == "" or before.rstrip().endswith(("=", "&&", "||", "begin")):
+                opens += 1
+        else:
+            opens += 1
+    assert opens == ends, f"{opens} block openers but {ends} `end`s"
+    # names used by the overrides are defined in the file
+    defined = set(re.findall(r"^\s*(?:function\s+)?([A-Za-z_][\w!]*)\s*(?:\{[^}]*\})?\(", src, re.M))
+    for name in ("fused_sweep!", "fused_sweep_mpi!", "swap_state!", "rank_group", "sweep_lag", "fused_state", "unique_id",
+                 "halo_exchange_start!", "halo_exchange_finish!", "halo_exchange_finish_edge!", "edge_context", "edge_dt",
+                 "edge_join!", "dt_allreduce!", "TileGroup", "HaloDesc", "check", "fn"):
+        assert name in defined, f"{name} is called but never defined"
