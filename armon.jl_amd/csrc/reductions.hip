@@ -90,6 +90,7 @@ inline void reduce_grid(const armon_ctx* ctx, const armon_range& r, dim3& grid)
 {
     int64_t gx = (r.row_len + kBlock - 1) / kBlock;
     if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
     int64_t target = (int64_t)ctx->n_cu * 8;
     int64_t gy = (target + gx - 1) / gx;
     if (gy > r.col_len) gy = r.col_len;
@@ -105,17 +106,21 @@ template <typename T>
 int dtCFL_async_impl(armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, const T* v, const T* c, T* result_dev)
 {
     ARMON_REQUIRE(ctx != nullptr, "ctx is NULL");
-    ARMON_REQUIRE(range_ok(r) && !range_empty(r), "dtCFL needs a non-empty range");
+    ARMON_REQUIRE(range_ok(r), "invalid range");
     ARMON_REQUIRE(u && v && c && result_dev, "NULL array");
-    dim3 grid;
-    reduce_grid(ctx, r, grid);
-    const int64_t n = (int64_t)grid.x * grid.y;
-    int rc = ensure_partials(ctx, (size_t)n * 2);
+    // the minimum over no cell is +inf (the reference's mapreduce has init = Inf, ref src/reductions.jl:79-87): an empty
+    // range folds zero partials
+    dim3 grid(1, 1, 1);
+    if (!range_empty(r)) reduce_grid(ctx, r, grid);
+    const int64_t n = range_empty(r) ? 0 : (int64_t)grid.x * grid.y;
+    int rc = ensure_partials(ctx, (size_t)(n > 0 ? n : 1) * 2);
     if (rc != ARMON_OK) return rc;
     T* partials = reinterpret_cast<T*>(ctx->partials);
-    hipLaunchKernelGGL(k_dtCFL_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, dx, dy, u, v, c, partials);
-    rc = check_launch("dtCFL_partial");
-    if (rc != ARMON_OK) return rc;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_dtCFL_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, dx, dy, u, v, c, partials);
+        rc = check_launch("dtCFL_partial");
+        if (rc != ARMON_OK) return rc;
+    }
     hipLaunchKernelGGL((k_fold<op_min, 1, T>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, n, T(1.0), result_dev);
     return check_launch("dtCFL_fold");
 }

@@ -301,6 +301,49 @@ def test_empty_range_and_bad_args(dev, L):
     assert b"limiter" in L.armon_hip_last_error()
 
 
+@pytest.mark.parametrize("suffix", ["", "_f32"])
+@pytest.mark.parametrize("empty", [dict(col_len=0, row_len=8), dict(col_len=6, row_len=0)], ids=["no-rows", "no-columns"])
+def test_every_kernel_accepts_an_empty_range(dev, L, empty, suffix):
+    """Empty inputs: every range-taking entry point, in both precisions, is a no-op on a range without rows or without
+    columns (the reference's step ranges can be empty, e.g. `1:0` borders of a 1-cell-wide block) — it returns 0, launches
+    nothing that writes, and the reductions return their neutral element."""
+    from armon_amd._lib import Range, SIGNATURES
+    flt = np.float32 if suffix else np.float64
+    cflt = C.c_float if suffix else C.c_double
+    marker = np.arange(16 * 16, dtype=flt) + 1
+    a = dev.from_host(marker)
+    p = C.c_void_p(a.ptr)
+    r = Range(16 * 2 + 2, 16, empty["col_len"], 0, empty["row_len"])
+    names = ["perfect_gas_EOS", "bizarrium_EOS", "acoustic", "acoustic_GAD", "cell_update", "advection_first_order",
+             "advection_second_order", "euler_projection", "boundary_conditions", "dtCFL_async"]
+    for name in names:
+        _res, argtypes = SIGNATURES["armon_hip_" + name + suffix]
+        args = []
+        for t in argtypes[2:]:
+            if t is C.c_void_p:
+                args.append(p)
+            elif t in (C.c_double, C.c_float):
+                args.append(t(0.1))
+            elif t is C.c_int64:
+                args.append(C.c_int64(1))
+            else:
+                args.append(C.c_int(1))            # limiter tag / nghost
+        assert getattr(L, "armon_hip_" + name + suffix)(dev.ctx, r, *args) == 0, (name, L.armon_hip_last_error())
+    vars_ = (C.c_void_p * 7)(*[a.ptr] * 7)
+    for name in ("pack_to_array", "unpack_from_array"):
+        assert getattr(L, "armon_hip_" + name + suffix)(dev.ctx, r, 4, 8, p, 7, vars_) == 0, name
+    out = cflt(-1.)
+    assert getattr(L, "armon_hip_dtCFL" + suffix)(dev.ctx, r, cflt(0.1), cflt(0.1), p, p, p, C.byref(out)) == 0
+    assert np.isinf(out.value) and out.value > 0                       # the minimum over nothing
+    cons = (cflt * 2)(-1., -1.)
+    assert getattr(L, "armon_hip_conservation_vars" + suffix)(dev.ctx, r, cflt(0.5), p, p, C.byref(cons)) == 0
+    assert tuple(cons) == (0., 0.)                                     # the sum over nothing
+    dev.wait()
+    got = a.to_host()
+    # dtCFL_async writes its scalar (+inf) where it is told to: element 0 of the marker array here
+    assert np.isinf(got[0]) and np.array_equal(got[1:], marker[1:])
+
+
 @pytest.mark.parametrize("test", ["Sod", "Sod_circ", "Bizarrium", "Sedov", "DebugIndexes"])
 def test_init_test(dev, L, oracle, test):
     import armon_amd
