@@ -19,6 +19,7 @@ from armon_amd.solver import BlockGrid, init_test, sweep_desc
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=16384)
+ap.add_argument("--shape", default=None, metavar="NXxNY", help="non-square block (overrides --n)")
 ap.add_argument("--rounds", type=int, default=20)
 ap.add_argument("--test", default="Sod")
 ap.add_argument("--exact", action="store_true")
@@ -32,12 +33,13 @@ ap.add_argument("--copy", action="store_true", help="also time armon_hip_stream_
 ap.add_argument("libs", nargs="+", help="name=path")
 args = ap.parse_args()
 
-params = armon_amd.ArmonParameters(test=args.test, N=(args.n, args.n), silent=5, maxcycle=10, exact_arithmetic=args.exact,
+shape = tuple(int(v) for v in args.shape.lower().split("x")) if args.shape else (args.n, args.n)
+params = armon_amd.ArmonParameters(test=args.test, N=shape, silent=5, maxcycle=10, exact_arithmetic=args.exact,
                                    scheme=args.scheme, projection=args.projection, data_type="float32" if args.f32 else "float64")
 grid = BlockGrid(params)
 init_test(params, grid)
 params.wait()
-dx = params.domain_size[0] / args.n
+dx = params.domain_size[0] / shape[0]
 dt = 0.3 * dx
 envs = {}
 for part in filter(None, args.env.split(";")):
@@ -88,4 +90,4 @@ for (axis, name), v in res.items():
     med = statistics.median(v)
     base.setdefault(axis, med)
     print(f"sweep_{axis} {name:12s}: median {med:7.3f} ms  min {min(v):7.3f}  max {max(v):7.3f}   "
-          f"{(32 if args.f32 else 64) * args.n * args.n / med / 1e6:7.1f} GB/s   x{med / base[axis]:.3f} vs first")
+          f"{(32 if args.f32 else 64) * shape[0] * shape[1] / med / 1e6:7.1f} GB/s   x{med / base[axis]:.3f} vs first")
