@@ -1,5 +1,4 @@
 """Multi-process tests of the N>1 path on CPU: world_size 2 over gloo (ref test/mpi.jl design)."""
-import os
 import socket
 
 import pytest

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import armon_amd
-from armon_amd.blocking import Axis, BlockSize, DomainRange, Side, StepRange, axis_of, compute_steps_ranges
+from armon_amd.blocking import Axis, BlockSize, Side, StepRange, axis_of, compute_steps_ranges
 from armon_amd.parameters import ArmonParameters, cart_coords, cart_neighbours, proc_grid_for
 from armon_amd.solver import GlobalTimeStep, split_axes
 
