@@ -14,6 +14,7 @@ using namespace armon;
 namespace {
 
 using red::kWave;
+using red::op_max;
 using red::op_min;
 using red::op_sum;
 
@@ -24,24 +25,49 @@ __device__ __forceinline__ T block_reduce(T v, T* lds)
 }
 
 // ---- a11: dtCFL (ref src/reductions.jl:2-53) -------------------------------------------------------
+// min over the cells of min(dx / a, dy / b), a = max(|u+c|, |u-c|), b = max(|v+c|, |v-c|). A correctly rounded division
+// is monotone in its divisor, so that minimum is min(dx / max a, dy / max b) — the same bits with two divisions per
+// LAUNCH instead of two per cell (the fused sweeps reduce their CFL step the same way, fused_sweep_impl.hpp).
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_dtCFL_partial(armon_range r, T dx, T dy, const T* __restrict__ u,
-                const T* __restrict__ v, const T* __restrict__ c,
+k_dtCFL_partial(armon_range r, const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ c,
                 T* __restrict__ partials)
 {
     __shared__ T lds[kBlock / kWave];
-    T acc = T(INFINITY);
+    T au = T(0.), av = T(0.);
     for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
         const int64_t base = r.col_start + j * r.col_step + r.row_start;
         for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < r.row_len;
              k += (int64_t)gridDim.x * blockDim.x) {
             const int64_t i = base + k;
-            acc = phys::mn(acc, phys::dt_cfl_cell(u[i], v[i], c[i], dx, dy));
+            const T uu = u[i], vv = v[i], cc = c[i];
+            au = phys::mx(au, phys::abs_(phys::mx(phys::abs_(uu + cc), phys::abs_(uu - cc))));
+            av = phys::mx(av, phys::abs_(phys::mx(phys::abs_(vv + cc), phys::abs_(vv - cc))));
         }
     }
-    T res = block_reduce<op_min>(acc, lds);
-    if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = res;
+    const T ru = block_reduce<op_max>(au, lds);
+    const T rv = block_reduce<op_max>(av, lds);
+    if (threadIdx.x == 0) {
+        const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partials[2 * b] = ru;
+        partials[2 * b + 1] = rv;
+    }
+}
+
+// max over the n partial pairs, then the two divisions; n = 0: dx / 0 = +inf, the minimum over no cell
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+k_dtCFL_fold(const T* __restrict__ partials, int64_t n, T dx, T dy, T* __restrict__ out)
+{
+    __shared__ T lds[kBlock / kWave];
+    T au = T(0.), av = T(0.);
+    for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
+        au = phys::mx(au, partials[2 * k]);
+        av = phys::mx(av, partials[2 * k + 1]);
+    }
+    au = block_reduce<op_max>(au, lds);
+    av = block_reduce<op_max>(av, lds);
+    if (threadIdx.x == 0) out[0] = phys::mn(dx / au, dy / av);
 }
 
 template <typename OP, int NOUT, typename T>
@@ -117,11 +143,11 @@ int dtCFL_async_impl(armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, cons
     if (rc != ARMON_OK) return rc;
     T* partials = reinterpret_cast<T*>(ctx->partials);
     if (n > 0) {
-        hipLaunchKernelGGL(k_dtCFL_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, dx, dy, u, v, c, partials);
+        hipLaunchKernelGGL(k_dtCFL_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, u, v, c, partials);
         rc = check_launch("dtCFL_partial");
         if (rc != ARMON_OK) return rc;
     }
-    hipLaunchKernelGGL((k_fold<op_min, 1, T>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, n, T(1.0), result_dev);
+    hipLaunchKernelGGL(k_dtCFL_fold<T>, dim3(1), dim3(kBlock), 0, ctx->stream, partials, n, dx, dy, result_dev);
     return check_launch("dtCFL_fold");
 }
 
