@@ -1,5 +1,5 @@
 import cProfile, pstats, sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import armon_amd as A
 p = A.ArmonParameters(test='Sod', N=(1000, 1000), silent=5)
 A.armon(p)   # warm
