@@ -122,7 +122,11 @@ SIGNATURES = {
     "armon_hip_mgpu_init": (_ci, [_ci, _ci, C.POINTER(_ci), C.POINTER(_vp)]),
     "armon_hip_mgpu_unique_id": (_ci, [_vp]),
     "armon_hip_mgpu_init_rank": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, C.POINTER(_vp)]),
+    "armon_hip_mgpu_prepare_rank": (_ci, [_ci, _ci, _ci, _ci, _vp, C.POINTER(_vp)]),
+    "armon_hip_mgpu_connect": (_ci, [_vp, _vp]),
     "armon_hip_mgpu_destroy": (_ci, [_vp]),
+    "armon_hip_mgpu_set_periodic": (_ci, [_vp, _ci, _ci]),
+    "armon_hip_mgpu_force_peer_copy": (_ci, [_vp, _ci]),
     "armon_hip_mgpu_set_chaos": (_ci, [_vp, C.c_uint, C.c_uint64]),
     "armon_hip_mgpu_n_local": (_ci, [_vp]),
     "armon_hip_mgpu_ctx": (_vp, [_vp, _ci]),

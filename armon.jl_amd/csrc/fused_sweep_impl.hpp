@@ -165,8 +165,9 @@ struct cfl_track {
     real au = 0, av = 0;
     __device__ __forceinline__ void add(real u, real v, real c)
     {
-        au = phys::mx(au, phys::abs_(phys::mx(phys::abs_(u + c), phys::abs_(u - c))));
-        av = phys::mx(av, phys::abs_(phys::mx(phys::abs_(v + c), phys::abs_(v - c))));
+        // amax: unsigned maximum of the bit patterns — the same maximum for these non-negative values, and a NaN sticks
+        au = phys::amax(au, phys::abs_(phys::mx(phys::abs_(u + c), phys::abs_(u - c))));
+        av = phys::amax(av, phys::abs_(phys::mx(phys::abs_(v + c), phys::abs_(v - c))));
     }
 };
 
@@ -192,8 +193,8 @@ k_fold_pairs(const real* __restrict__ partials, int64_t n, real* __restrict__ ou
     real au = 0, av = 0;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const vec2 v = ld2(partials + 2 * k);
-        au = phys::mx(au, v.x);
-        av = phys::mx(av, v.y);
+        au = phys::amax(au, v.x);
+        av = phys::amax(av, v.y);
     }
     au = red::block_reduce<red::op_max, 4>(au, lds, threadIdx.x);
     av = red::block_reduce<red::op_max, 4>(av, lds, threadIdx.x);
@@ -210,14 +211,14 @@ k_fold_dt(const real* __restrict__ partials, int64_t n_blocks, real dx, real dy,
     __shared__ real lds[4];
     real au = 0, av = 0;
     for (int64_t k = threadIdx.x; k < n_blocks; k += blockDim.x) {
-        au = phys::mx(au, partials[2 * k]);
-        av = phys::mx(av, partials[2 * k + 1]);
+        au = phys::amax(au, partials[2 * k]);
+        av = phys::amax(av, partials[2 * k + 1]);
     }
     au = red::block_reduce<red::op_max, 4>(au, lds, threadIdx.x);
     av = red::block_reduce<red::op_max, 4>(av, lds, threadIdx.x);
     if (threadIdx.x == 0) {
-        const real dt = phys::mn(dx / au, dy / av);
-        out[0] = accumulate ? phys::mn(out[0], dt) : dt;
+        const real dt = phys::mn_nan(dx / au, dy / av);             // a NaN maximum gives a NaN step, and it wins
+        out[0] = accumulate ? phys::mn_nan(out[0], dt) : dt;
     }
 }
 

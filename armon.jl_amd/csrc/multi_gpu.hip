@@ -128,6 +128,9 @@ struct tile_t {
 struct armon_mgpu {
     int px = 1, py = 1;
     bool rccl = false;
+    bool periodic[2] = {false, false};           // test aid (armon_hip_mgpu_set_periodic): out-of-grid neighbours wrap
+    bool force_peer = false;                     // test aid: hipMemcpyPeerAsync even between tiles of one device
+    int rank = 0, device = 0;                    // rank mode: kept between _prepare_rank and _connect
     std::vector<tile_t> tiles;                   // local tiles; in-process: all of them, index == rank
     // in-process reductions: gather on tiles[0]'s device
     double* red_buf = nullptr;                   // [n_tiles] (doubles; fp32 runs use the first half of each slot)
@@ -162,13 +165,18 @@ void chaos(armon_mgpu* g, hipStream_t stream)
     (void)hipGetLastError();
 }
 
-// ref MPI.Cart_coords / Cart_shift on a non-periodic px × py grid, last dimension fastest (src/parameters.jl:441-447)
-void set_topology(tile_t& t, int rank, int px, int py)
+// ref MPI.Cart_coords / Cart_shift on a px × py grid, last dimension fastest (src/parameters.jl:441-447). The reference's
+// grid is never periodic (MPI.Cart_create's default, :432); `periodic` is the test aid of armon_hip_mgpu_set_periodic.
+void set_topology(tile_t& t, int rank, int px, int py, const bool periodic[2])
 {
     t.rank = rank;
     t.cx = rank / py;
     t.cy = rank % py;
-    auto at = [&](int cx, int cy) { return (cx < 0 || cx >= px || cy < 0 || cy >= py) ? -1 : cx * py + cy; };
+    auto at = [&](int cx, int cy) {
+        if (periodic[0]) cx = (cx + px) % px;
+        if (periodic[1]) cy = (cy + py) % py;
+        return (cx < 0 || cx >= px || cy < 0 || cy >= py) ? -1 : cx * py + cy;
+    };
     t.nb[ARMON_SIDE_LEFT] = at(t.cx - 1, t.cy);
     t.nb[ARMON_SIDE_RIGHT] = at(t.cx + 1, t.cy);
     t.nb[ARMON_SIDE_BOTTOM] = at(t.cx, t.cy - 1);
@@ -249,26 +257,61 @@ int check_desc(const armon_mgpu* g, int axis, const armon_halo_desc* d)
     return ARMON_OK;
 }
 
-template <typename T>
-int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
+// What an exchange_start that fails half-way leaves behind: sides marked in flight whose transfer was never posted. Every
+// later start would then refuse ("already started") and a finish would unpack a buffer nothing was received into, so the
+// group would be unusable after one recoverable error. Drain the local streams (a pack or a copy of this call may be
+// running) and clear the marks of the sides this call touched.
+void abandon_start(armon_mgpu* g, int s0)
 {
-    int rc = check_desc(g, axis, d);
-    if (rc != ARMON_OK) return rc;
+    for (tile_t& t : g->tiles) {
+        (void)hipSetDevice(t.device);
+        (void)hipStreamSynchronize(t.ctx->stream);
+        (void)hipStreamSynchronize(t.xfer);
+        for (int s = s0; s < s0 + 2; s++) t.inflight[s] = 0;
+    }
+    (void)hipGetLastError();
+}
+
+template <typename T>
+int exchange_start_impl(armon_mgpu* g, int axis, const armon_halo_desc* d, bool& touched)
+{
     const int s0 = first_side(axis);
     const size_t nt = g->tiles.size();
-    // 1. pack every remote face of every local tile on its compute stream
+    // 0. everything that can be refused is refused BEFORE anything is packed or marked: the descriptors (check_desc, by the
+    //    caller), an exchange still in flight, the sizes the two ends of a face expect (in-process: both descriptors are
+    //    here), and the face buffers (their growth drains the streams and allocates)
     for (size_t k = 0; k < nt; k++) {
         tile_t& t = g->tiles[k];
         for (int s = s0; s < s0 + 2; s++) {
             if (t.nb[s] < 0) continue;
             ARMON_REQUIRE(t.inflight[s] == 0, "halo exchange of side %d already started (finish it first)", s);
-            armon_range border;
             int64_t face;
-            rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, &border, nullptr, &face);
+            int rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, nullptr, nullptr, &face);
             if (rc != ARMON_OK) return rc;
             const size_t bytes = (size_t)face * d[k].nghost * d[k].nvars * sizeof(T);
+            if (!g->rccl) {
+                const armon_halo_desc& dn = d[t.nb[s]];
+                int64_t nface;
+                rc = armon_hip_halo_ranges(dn.nx, dn.ny, dn.nghost, opposite(s), nullptr, nullptr, &nface);
+                if (rc != ARMON_OK) return rc;
+                const size_t nbytes = (size_t)nface * dn.nghost * dn.nvars * sizeof(T);
+                ARMON_REQUIRE(nbytes == bytes, "tiles %d and %d disagree on the size of their common face (%zu vs %zu bytes)",
+                              t.rank, g->tiles[t.nb[s]].rank, bytes, nbytes);
+            }
             rc = ensure_face_buffers(g, t, s, bytes);
             if (rc != ARMON_OK) return rc;
+        }
+    }
+    // 1. pack every remote face of every local tile on its compute stream
+    for (size_t k = 0; k < nt; k++) {
+        tile_t& t = g->tiles[k];
+        for (int s = s0; s < s0 + 2; s++) {
+            if (t.nb[s] < 0) continue;
+            armon_range border;
+            int64_t face;
+            int rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, &border, nullptr, &face);
+            if (rc != ARMON_OK) return rc;
+            const size_t bytes = (size_t)face * d[k].nghost * d[k].nvars * sizeof(T);
             ARMON_HIP_TRY(hipSetDevice(t.device));
             // the previous message of this side must have left send[s] (in-process: the neighbour's copy event; RCCL:
             // our own transfer stream's event, which finish already made the compute stream wait for)
@@ -277,6 +320,7 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
                 if (n.rec_recv[opposite(s)]) ARMON_HIP_TRY(hipStreamWaitEvent(t.ctx->stream, n.e_recv[opposite(s)], 0));
             }
             chaos(g, t.ctx->stream);
+            touched = true;
             rc = pack<T>(t.ctx, border, d[k].nghost, face, static_cast<T*>(t.send[s]), d[k].nvars,
                          reinterpret_cast<const T* const*>(d[k].vars));
             if (rc != ARMON_OK) return rc;
@@ -300,12 +344,18 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
                 if (t.rec_unpack[s]) ARMON_HIP_TRY(hipStreamWaitEvent(t.xfer, t.e_unpack[s], 0));   // recv[s] free again
             }
             const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+            // Sends in side order, receives in the OPPOSITE order: RCCL matches the k-th send to a peer with that peer's
+            // k-th receive from us. With two different neighbours the order is irrelevant; when both sides have the SAME
+            // peer (a periodic grid of one or two tiles along the axis — armon_hip_mgpu_set_periodic — the rank itself
+            // included) our low face must land in the peer's HIGH ghosts, i.e. in the receive it posts second-to-last.
             ARMON_RCCL_TRY(g_rccl.GroupStart());
             for (int s = s0; s < s0 + 2; s++) {
                 if (!t.inflight[s]) continue;
-                const size_t count = t.inflight[s] / sizeof(T);
-                ARMON_RCCL_TRY(g_rccl.Send(t.send[s], count, dt, t.nb[s], g->comm_halo, t.xfer));
-                ARMON_RCCL_TRY(g_rccl.Recv(t.recv[s], count, dt, t.nb[s], g->comm_halo, t.xfer));
+                ARMON_RCCL_TRY(g_rccl.Send(t.send[s], t.inflight[s] / sizeof(T), dt, t.nb[s], g->comm_halo, t.xfer));
+            }
+            for (int s = s0 + 1; s >= s0; s--) {
+                if (!t.inflight[s]) continue;
+                ARMON_RCCL_TRY(g_rccl.Recv(t.recv[s], t.inflight[s] / sizeof(T), dt, t.nb[s], g->comm_halo, t.xfer));
             }
             ARMON_RCCL_TRY(g_rccl.GroupEnd());
             for (int s = s0; s < s0 + 2; s++) {
@@ -318,11 +368,9 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
                 if (!t.inflight[s]) continue;
                 tile_t& n = g->tiles[t.nb[s]];
                 const int os = opposite(s);
-                ARMON_REQUIRE(n.inflight[os] == t.inflight[s], "tiles %d and %d disagree on the size of their common face "
-                              "(%zu vs %zu bytes)", t.rank, n.rank, t.inflight[s], n.inflight[os]);
                 ARMON_HIP_TRY(hipStreamWaitEvent(t.xfer, n.e_pack[os], 0));                          // neighbour packed
                 if (t.rec_unpack[s]) ARMON_HIP_TRY(hipStreamWaitEvent(t.xfer, t.e_unpack[s], 0));   // recv[s] free again
-                if (n.device == t.device)
+                if (n.device == t.device && !g->force_peer)
                     ARMON_HIP_TRY(hipMemcpyAsync(t.recv[s], n.send[os], t.inflight[s], hipMemcpyDeviceToDevice, t.xfer));
                 else
                     ARMON_HIP_TRY(hipMemcpyPeerAsync(t.recv[s], t.device, n.send[os], n.device, t.inflight[s], t.xfer));
@@ -332,6 +380,17 @@ int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
         }
     }
     return ARMON_OK;
+}
+
+template <typename T>
+int exchange_start(armon_mgpu* g, int axis, const armon_halo_desc* d)
+{
+    int rc = check_desc(g, axis, d);
+    if (rc != ARMON_OK) return rc;
+    bool touched = false;
+    rc = exchange_start_impl<T>(g, axis, d, touched);
+    if (rc != ARMON_OK && touched) abandon_start(g, first_side(axis));     // the message of `rc` stays in last_error
+    return rc;
 }
 
 template <typename T>
@@ -412,6 +471,13 @@ int edge_join(armon_mgpu* g, T* const* dt_dev)
     return ARMON_OK;
 }
 
+template <typename T>
+__global__ void k_nan_to_neg_inf(T* __restrict__ x)
+{
+    const T v = *x;
+    if (v != v) *x = -T(INFINITY);
+}
+
 // every tile on ONE device (up to 64 of them): lane k reads tile k's scalar, the wave folds, lane k writes the minimum back
 constexpr int kMaxDirect = 64;
 struct dt_ptrs { void* p[kMaxDirect]; };
@@ -438,6 +504,13 @@ int dt_allreduce(armon_mgpu* g, T* const* dt_dev)
     if (g->rccl) {
         tile_t& t = g->tiles[0];
         ARMON_HIP_TRY(hipSetDevice(t.device));
+        // ncclMin is free to drop a NaN operand; -inf survives any minimum and fails the host's validity check just as well
+        // (ref src/solver_state.jl:123-124: `!isfinite(new_dt) || new_dt <= 0`)
+        hipLaunchKernelGGL(k_nan_to_neg_inf<T>, dim3(1), dim3(1), 0, t.ctx->stream, dt_dev[0]);
+        {
+            int rc = check_launch("nan_to_neg_inf");
+            if (rc != ARMON_OK) return rc;
+        }
         ARMON_RCCL_TRY(g_rccl.AllReduce(dt_dev[0], dt_dev[0], 1, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclMin,
                                         g->comm_red, t.ctx->stream));
         return ARMON_OK;
@@ -446,7 +519,7 @@ int dt_allreduce(armon_mgpu* g, T* const* dt_dev)
     tile_t& root = g->tiles[0];
     for (size_t k = 0; k < nt; k++) chaos(g, g->tiles[k].ctx->stream);
     chaos(g, root.xfer);
-    bool one_device = nt <= (size_t)kMaxDirect;
+    bool one_device = nt <= (size_t)kMaxDirect && !g->force_peer;    // force_peer: take the several-device path below
     for (size_t k = 0; k < nt; k++) one_device = one_device && g->tiles[k].device == root.device;
     if (one_device) {
         // one kernel on tile 0's transfer stream instead of 2·nt serialized copies (the chain between two cycles)
@@ -478,7 +551,7 @@ int dt_allreduce(armon_mgpu* g, T* const* dt_dev)
     for (size_t k = 0; k < nt; k++) {
         tile_t& t = g->tiles[k];
         ARMON_HIP_TRY(hipStreamWaitEvent(root.xfer, t.e_red, 0));
-        if (t.device == root.device)
+        if (t.device == root.device && !g->force_peer)
             ARMON_HIP_TRY(hipMemcpyAsync(slots + k * stride, dt_dev[k], sizeof(T), hipMemcpyDeviceToDevice, root.xfer));
         else
             ARMON_HIP_TRY(hipMemcpyPeerAsync(slots + k * stride, root.device, dt_dev[k], t.device, sizeof(T), root.xfer));
@@ -490,7 +563,7 @@ int dt_allreduce(armon_mgpu* g, T* const* dt_dev)
     }
     for (size_t k = 0; k < nt; k++) {
         tile_t& t = g->tiles[k];
-        if (t.device == root.device)
+        if (t.device == root.device && !g->force_peer)
             ARMON_HIP_TRY(hipMemcpyAsync(dt_dev[k], slots + k * stride, sizeof(T), hipMemcpyDeviceToDevice, root.xfer));
         else
             ARMON_HIP_TRY(hipMemcpyPeerAsync(dt_dev[k], t.device, slots + k * stride, root.device, sizeof(T), root.xfer));
@@ -555,7 +628,7 @@ int armon_hip_mgpu_init(int px, int py, const int* device_ids, armon_mgpu** out)
     int rc = ARMON_OK;
     for (int r = 0; r < nt && rc == ARMON_OK; r++) {
         tile_t& t = g->tiles[r];
-        set_topology(t, r, px, py);
+        set_topology(t, r, px, py, g->periodic);
         t.device = device_ids ? device_ids[r] : 0;
         rc = armon_hip_init(t.device, nullptr, &t.ctx);
         if (rc == ARMON_OK) rc = make_tile_resources(t);
@@ -594,21 +667,26 @@ int armon_hip_mgpu_unique_id(void* id)
     return ARMON_OK;
 }
 
-int armon_hip_mgpu_init_rank(int px, int py, int rank, int device_id, void* stream, const void* id, armon_mgpu** out)
+// One process per GPU, in two steps so that the host can agree on readiness in between: _prepare_rank does everything that
+// is LOCAL to this process (RCCL symbols, context, streams, events, scratch) and can fail on one rank alone; _connect is the
+// collective part (ncclCommInitRank of the two communicators) and must be entered by every rank or by none — a rank that
+// skipped it after a local failure would leave the others blocked in it for ever.
+int armon_hip_mgpu_prepare_rank(int px, int py, int rank, int device_id, void* stream, armon_mgpu** out)
 {
     ARMON_REQUIRE(out, "group out pointer is NULL");
     *out = nullptr;
     ARMON_REQUIRE(px >= 1 && py >= 1 && rank >= 0 && rank < px * py, "invalid rank %d of a %d x %d tile grid", rank, px, py);
-    ARMON_REQUIRE(id, "id is NULL");
     int rc = load_rccl();
     if (rc != ARMON_OK) return rc;
     armon_mgpu* g = new armon_mgpu();
     g->px = px;
     g->py = py;
     g->rccl = true;
+    g->rank = rank;
+    g->device = device_id;
     g->tiles.resize(1);
     tile_t& t = g->tiles[0];
-    set_topology(t, rank, px, py);
+    set_topology(t, rank, px, py, g->periodic);
     t.device = device_id;
     rc = armon_hip_init(device_id, stream, &t.ctx);
     if (rc == ARMON_OK) rc = make_tile_resources(t);
@@ -617,15 +695,38 @@ int armon_hip_mgpu_init_rank(int px, int py, int rank, int device_id, void* stre
         if (e == hipSuccess) e = hipHostMalloc((void**)&g->red_scratch_host, 16 * sizeof(double), hipHostMallocDefault);
         if (e != hipSuccess) rc = fail_hip(e, "group allocation");
     }
-    if (rc == ARMON_OK) {
-        const ncclUniqueId* ids = static_cast<const ncclUniqueId*>(id);
-        ncclResult_t r = g_rccl.CommInitRank(&g->comm_halo, px * py, ids[0], rank);
-        if (r == ncclSuccess) r = g_rccl.CommInitRank(&g->comm_red, px * py, ids[1], rank);
-        if (r != ncclSuccess) {
-            set_error("ncclCommInitRank: %s", g_rccl.GetErrorString(r));
-            rc = ARMON_ERR_HIP;
-        }
+    if (rc != ARMON_OK) {
+        armon_hip_mgpu_destroy(g);
+        return rc;
     }
+    *out = g;
+    return ARMON_OK;
+}
+
+int armon_hip_mgpu_connect(armon_mgpu* g, const void* id)
+{
+    ARMON_REQUIRE(g && id, "NULL argument");
+    ARMON_REQUIRE(g->rccl && !g->comm_halo && !g->comm_red, "not a prepared, unconnected rank group");
+    ARMON_HIP_TRY(hipSetDevice(g->device));
+    const ncclUniqueId* ids = static_cast<const ncclUniqueId*>(id);
+    ncclResult_t r = g_rccl.CommInitRank(&g->comm_halo, g->px * g->py, ids[0], g->rank);
+    if (r == ncclSuccess) r = g_rccl.CommInitRank(&g->comm_red, g->px * g->py, ids[1], g->rank);
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+        return ARMON_ERR_HIP;
+    }
+    return ARMON_OK;
+}
+
+int armon_hip_mgpu_init_rank(int px, int py, int rank, int device_id, void* stream, const void* id, armon_mgpu** out)
+{
+    ARMON_REQUIRE(out, "group out pointer is NULL");
+    *out = nullptr;
+    ARMON_REQUIRE(id, "id is NULL");
+    armon_mgpu* g = nullptr;
+    int rc = armon_hip_mgpu_prepare_rank(px, py, rank, device_id, stream, &g);
+    if (rc != ARMON_OK) return rc;
+    rc = armon_hip_mgpu_connect(g, id);
     if (rc != ARMON_OK) {
         armon_hip_mgpu_destroy(g);
         return rc;
@@ -674,6 +775,29 @@ int armon_hip_mgpu_set_chaos(armon_mgpu* g, unsigned max_delay_us, uint64_t seed
     ARMON_REQUIRE(max_delay_us <= 20000, "delays above 20 ms are not a test any more");
     g->chaos_us = max_delay_us;
     g->chaos_rng = seed ? seed : 0x9E3779B97F4A7C15ull;
+    return ARMON_OK;
+}
+
+// Test aids for the transport: a periodic topology (out-of-grid neighbours wrap around, per axis) makes a 1 x 1 rank group
+// its own left/right/bottom/top neighbour, so that ONE GPU executes the real ncclSend/ncclRecv pairs of exchange_start; and
+// force_peer_copy sends an in-process group's faces through hipMemcpyPeerAsync even when both tiles share a device. The
+// reference's process grid is never periodic (ref src/parameters.jl:432: MPI.Cart_create without `periodic`).
+int armon_hip_mgpu_set_periodic(armon_mgpu* g, int periodic_x, int periodic_y)
+{
+    ARMON_REQUIRE(g, "NULL argument");
+    for (const tile_t& t : g->tiles)
+        for (int s = 0; s < kSides; s++) ARMON_REQUIRE(t.inflight[s] == 0, "a halo exchange is in flight");
+    g->periodic[0] = periodic_x != 0;
+    g->periodic[1] = periodic_y != 0;
+    for (tile_t& t : g->tiles) set_topology(t, t.rank, g->px, g->py, g->periodic);
+    return ARMON_OK;
+}
+
+int armon_hip_mgpu_force_peer_copy(armon_mgpu* g, int on)
+{
+    ARMON_REQUIRE(g, "NULL argument");
+    ARMON_REQUIRE(!g->rccl, "peer copies are the transport of an in-process group (armon_hip_mgpu_init)");
+    g->force_peer = on != 0;
     return ARMON_OK;
 }
 

@@ -99,6 +99,24 @@ using xct::Den;
 template <typename T> __device__ __forceinline__ T mx(T x, T y) { return (y > x) ? y : x; }
 template <typename T> __device__ __forceinline__ T mn(T x, T y) { return (y > x) ? x : y; }
 
+// Running maximum of NON-NEGATIVE values in which a NaN sticks — what the dt/CFL reductions accumulate with. The
+// reference raises on the first non-finite time step (ref src/solver_state.jl:123-124), so a NaN sound speed or velocity
+// in ONE cell must reach the host, while mx() above drops a NaN operand on either side. For non-negative IEEE values the
+// order of the bit patterns as unsigned integers is the order of the values, with +inf above every finite value and every
+// (sign-cleared) NaN above +inf: an unsigned maximum of the bits is the same maximum, NaN wins, and stays.
+__device__ __forceinline__ double amax(double acc, double val)
+{
+    const unsigned long long a = (unsigned long long)__double_as_longlong(acc), b = (unsigned long long)__double_as_longlong(val);
+    return __longlong_as_double((long long)(b > a ? b : a));
+}
+__device__ __forceinline__ float amax(float acc, float val)
+{
+    const unsigned a = __float_as_uint(acc), b = __float_as_uint(val);
+    return __uint_as_float(b > a ? b : a);
+}
+// minimum in which a NaN on either side wins (folds of the dt/CFL reductions)
+template <typename T> __device__ __forceinline__ T mn_nan(T x, T y) { return (y < x || y != y) ? y : x; }
+
 __device__ __forceinline__ double sqrt_(double x) { return xct::sqrt_(x); }
 __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }

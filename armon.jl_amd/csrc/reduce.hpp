@@ -11,7 +11,9 @@ namespace red {
 constexpr int kWave = 64;
 
 struct op_min { template <typename T> __device__ static T id() { return T(INFINITY); } template <typename T> __device__ static T f(T a, T b) { return phys::mn(a, b); } };
-struct op_max { template <typename T> __device__ static T id() { return T(0.); } template <typename T> __device__ static T f(T a, T b) { return phys::mx(a, b); } };
+// maximum of NON-NEGATIVE values, NaN sticks (phys::amax): only the dt/CFL reductions use it, and a NaN in one cell has to
+// reach the host's validity check (ref src/solver_state.jl:123-124)
+struct op_max { template <typename T> __device__ static T id() { return T(0.); } template <typename T> __device__ static T f(T a, T b) { return phys::amax(a, b); } };
 struct op_sum { template <typename T> __device__ static T id() { return T(0.); } template <typename T> __device__ static T f(T a, T b) { return a + b; } };
 
 template <typename OP, typename T>

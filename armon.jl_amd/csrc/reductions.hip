@@ -41,8 +41,9 @@ k_dtCFL_partial(armon_range r, const T* __restrict__ u, const T* __restrict__ v,
              k += (int64_t)gridDim.x * blockDim.x) {
             const int64_t i = base + k;
             const T uu = u[i], vv = v[i], cc = c[i];
-            au = phys::mx(au, phys::abs_(phys::mx(phys::abs_(uu + cc), phys::abs_(uu - cc))));
-            av = phys::mx(av, phys::abs_(phys::mx(phys::abs_(vv + cc), phys::abs_(vv - cc))));
+            // amax: a NaN in one cell sticks (the reference's reduction ends in `Invalid time step`, ref src/solver_state.jl:123)
+            au = phys::amax(au, phys::abs_(phys::mx(phys::abs_(uu + cc), phys::abs_(uu - cc))));
+            av = phys::amax(av, phys::abs_(phys::mx(phys::abs_(vv + cc), phys::abs_(vv - cc))));
         }
     }
     const T ru = block_reduce<op_max>(au, lds);
@@ -62,12 +63,12 @@ k_dtCFL_fold(const T* __restrict__ partials, int64_t n, T dx, T dy, T* __restric
     __shared__ T lds[kBlock / kWave];
     T au = T(0.), av = T(0.);
     for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
-        au = phys::mx(au, partials[2 * k]);
-        av = phys::mx(av, partials[2 * k + 1]);
+        au = phys::amax(au, partials[2 * k]);
+        av = phys::amax(av, partials[2 * k + 1]);
     }
     au = block_reduce<op_max>(au, lds);
     av = block_reduce<op_max>(av, lds);
-    if (threadIdx.x == 0) out[0] = phys::mn(dx / au, dy / av);
+    if (threadIdx.x == 0) out[0] = phys::mn_nan(dx / au, dy / av);
 }
 
 template <typename OP, int NOUT, typename T>

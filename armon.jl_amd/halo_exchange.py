@@ -31,6 +31,11 @@ class HaloExchanger:
     def __init__(self, params, grid=None, host_arrays=None, max_vars=7):
         import torch
         import torch.distributed as dist
+        if any(getattr(params, "periodic", (False, False))):
+            # a periodic grid can make both sides of an axis talk to the SAME peer: batch_isend_irecv then depends on
+            # message order, which only the library's exchange arranges (multi_gpu.hip, exchange_start)
+            from ._lib import solver_error
+            solver_error("config", "periodic process grids (a test aid) need the native halo exchange")
         self.params = params
         self.grid = grid
         self.host_arrays = host_arrays
@@ -176,9 +181,10 @@ def setup(params, grid, native=None):
         from .multi_tile import NativeRcclExchanger
         comm, ok = None, 1.0
         try:
-            comm = NativeRcclExchanger(params, grid)
-        except (SolverException, RuntimeError, AssertionError):
+            comm = NativeRcclExchanger(params, grid)      # agrees on local readiness itself before its collective part
+        except (SolverException, RuntimeError, AssertionError) as e:
             ok = 0.0
+            params.native_halo_error = f"{type(e).__name__}: {e}"       # bench.py reports it
         flag = torch.tensor([ok], device=torch.device("cuda", params.device_id))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=params.global_comm)
         if float(flag.item()) == 1.0:

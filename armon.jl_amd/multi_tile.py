@@ -40,7 +40,10 @@ def _halo_descs(params_list, grids, names):
 class TileGroup:
     """All tiles of a ``P = (px, py)`` decomposition of one problem, in this process."""
 
-    def __init__(self, P, device_ids=None, **options):
+    def __init__(self, P, device_ids=None, force_peer_copy=False, **options):
+        """``periodic=(x, y)`` and ``force_peer_copy`` are test aids for the transport (``armon_hip_mgpu_set_periodic``,
+        ``armon_hip_mgpu_force_peer_copy``): wrap-around neighbours, and ``hipMemcpyPeerAsync`` for every face and dt
+        scalar even though the tiles share a device."""
         L = _lib.lib()
         self.P = (int(P[0]), int(P[1]))
         nt = self.P[0] * self.P[1]
@@ -49,6 +52,11 @@ class TileGroup:
         self.handle = C.c_void_p()
         check(L.armon_hip_mgpu_init(self.P[0], self.P[1], (C.c_int * nt)(*ids), C.byref(self.handle)))
         self._L = L
+        periodic = tuple(bool(v) for v in options.get("periodic", (False, False)))
+        if any(periodic):
+            check(L.armon_hip_mgpu_set_periodic(self.handle, int(periodic[0]), int(periodic[1])))
+        if force_peer_copy:
+            check(L.armon_hip_mgpu_force_peer_copy(self.handle, 1))
         for k in ("use_MPI", "device_id", "P"):
             options.pop(k, None)
         self.params, self.grids, self._edge_ctx, self._edge_dt = [], [], [], []
@@ -312,10 +320,25 @@ class NativeRcclExchanger:
         if not isinstance(obj[0], bytes):
             raise _lib.SolverException("cpp", f"rank 0 could not create the RCCL ids: {obj[0]}")
         ident = C.create_string_buffer(obj[0], _lib.MGPU_ID_BYTES)
-        dev = params.device                     # the tile's kernels keep running on the context the run already uses
-        self.handle = C.c_void_p()
-        check(L.armon_hip_mgpu_init_rank(params.proc_dims[0], params.proc_dims[1], params.rank, params.device_id,
-                                         C.c_void_p(dev.stream), ident, C.byref(self.handle)))
+        # Local part first (RCCL symbols, context, streams, scratch: it can fail on one rank alone), then the ranks agree
+        # over the launcher's group, and only then the collective ncclCommInitRank — entered by every rank or by none: a
+        # rank that skipped it after a local failure would leave the others blocked in it for ever.
+        self.handle, err = C.c_void_p(), None
+        try:
+            dev = params.device                 # the tile's kernels keep running on the context the run already uses
+            check(L.armon_hip_mgpu_prepare_rank(params.proc_dims[0], params.proc_dims[1], params.rank, params.device_id,
+                                                C.c_void_p(dev.stream), C.byref(self.handle)))
+            if any(params.periodic):
+                check(L.armon_hip_mgpu_set_periodic(self.handle, int(params.periodic[0]), int(params.periodic[1])))
+        except (_lib.SolverException, RuntimeError) as e:
+            err = e
+        ready = [None] * dist.get_world_size(group)
+        dist.all_gather_object(ready, err is None, group=group)
+        if not all(ready):
+            self.close()
+            raise _lib.SolverException("cpp", f"native RCCL group: local initialisation failed on rank(s) "
+                                              f"{[r for r, ok in enumerate(ready) if not ok]}" + (f": {err}" if err else ""))
+        check(L.armon_hip_mgpu_connect(self.handle, ident))
         # the group made its own context on that same stream; sweeps stay on params.device (same stream → same order)
         rank, coords, nb = C.c_int(), (C.c_int * 2)(), (C.c_int * 4)()
         check(L.armon_hip_mgpu_tile_info(self.handle, 0, C.byref(rank), C.byref(coords), C.byref(nb)))
@@ -361,6 +384,10 @@ class NativeRcclExchanger:
     def allreduce_min_device_async(self, scalar):
         ptrs = (C.c_void_p * 1)(scalar.ptr)
         check(self._fn("dt_allreduce")(self.handle, ptrs))
+
+    def set_chaos(self, max_delay_us, seed=0):
+        """Test aid: random busy-wait kernels in front of the group's stream operations (armon_hip_mgpu_set_chaos)."""
+        check(self._L.armon_hip_mgpu_set_chaos(self.handle, int(max_delay_us), int(seed)))
 
     def allreduce_host(self, values, op):
         v = (C.c_double * len(values))(*values)

@@ -119,12 +119,16 @@ class ArmonParameters:
     # gloo in CPU tests): `use_MPI=True` needs an initialised process group, `global_comm` may carry a
     # torch ProcessGroup. Default is False here because a single process owns a single GPU.
     def _init_MPI(self, use_MPI=False, P=(1, 1), reorder_grid=True, global_comm=None, gpu_aware=True,
-                  tile_of=None, **options):
+                  tile_of=None, periodic=(False, False), **options):
         """``tile_of=(rank, (px, py))``: this parameter set describes ONE tile of a px×py grid whose tiles all live in
         this process (``multi_tile.TileGroup`` over ``armon_hip_mgpu_init``): same partition and neighbours as an MPI
-        rank of the reference, no process group involved."""
+        rank of the reference, no process group involved. ``periodic=(x, y)``: TEST AID for the transport (the
+        reference's ``MPI.Cart_create`` is never periodic, ref src/parameters.jl:432) — neighbours wrap around along
+        that axis, so a 1×1 rank is its own neighbour and one GPU runs the real send/recv calls
+        (``armon_hip_mgpu_set_periodic``); only the library's native exchange supports it."""
         if tile_of is not None:
             P = tile_of[1]
+        self.periodic = (bool(periodic[0]), bool(periodic[1]))
         if len(P) != len(self.N):
             solver_error("config", f"Mismatched dimensions: expected a grid of {len(self.N)} processes, got: {len(P)}")
         self.use_MPI = bool(use_MPI)
@@ -142,7 +146,7 @@ class ArmonParameters:
                 solver_error("config", f"could not create a {P[0]}×{P[1]} cartesian topology "
                                        f"using {self.proc_size} processes")
             self.cart_coords = cart_coords(self.rank, self.proc_dims)
-            self.neighbours = cart_neighbours(self.cart_coords, self.proc_dims)
+            self.neighbours = cart_neighbours(self.cart_coords, self.proc_dims, self.periodic)
         elif tile_of is not None:
             self.proc_dims = tuple(int(p) for p in P)
             self.rank = int(tile_of[0])
@@ -150,8 +154,10 @@ class ArmonParameters:
             if not 0 <= self.rank < self.proc_size:
                 solver_error("config", f"tile {self.rank} is not part of a {P[0]}×{P[1]} grid")
             self.cart_coords = cart_coords(self.rank, self.proc_dims)
-            self.neighbours = cart_neighbours(self.cart_coords, self.proc_dims)
+            self.neighbours = cart_neighbours(self.cart_coords, self.proc_dims, self.periodic)
         else:
+            if any(self.periodic):
+                solver_error("config", "periodic=... needs use_MPI=true or a tile group: it describes the process grid")
             self.rank = 0
             self.proc_size = 1
             self.proc_dims = (1, 1)
@@ -314,20 +320,21 @@ def cart_coords(rank, dims):
     return (rank // dims[1], rank % dims[1])
 
 
-def cart_rank(coords, dims):
+def cart_rank(coords, dims, periodic=(False, False)):
+    coords = tuple(c % dims[d] if periodic[d] else c for d, c in enumerate(coords))
     if not all(0 <= coords[d] < dims[d] for d in range(2)):
         return PROC_NULL
     return coords[0] * dims[1] + coords[1]
 
 
-def cart_neighbours(coords, dims):
-    """ref src/parameters.jl:441-447 (MPI.Cart_shift along dim 0 = X, dim 1 = Y)."""
+def cart_neighbours(coords, dims, periodic=(False, False)):
+    """ref src/parameters.jl:441-447 (MPI.Cart_shift along dim 0 = X, dim 1 = Y); ``periodic``: test aid, see ``_init_MPI``."""
     cx, cy = coords
     return {
-        Side.Left: cart_rank((cx - 1, cy), dims),
-        Side.Right: cart_rank((cx + 1, cy), dims),
-        Side.Bottom: cart_rank((cx, cy - 1), dims),
-        Side.Top: cart_rank((cx, cy + 1), dims),
+        Side.Left: cart_rank((cx - 1, cy), dims, periodic),
+        Side.Right: cart_rank((cx + 1, cy), dims, periodic),
+        Side.Bottom: cart_rank((cx, cy - 1), dims, periodic),
+        Side.Top: cart_rank((cx, cy + 1), dims, periodic),
     }
 
 

@@ -199,6 +199,7 @@ class BlockGrid:
         rounds = max(1, int(getattr(params, "placement_rounds", 3))) if not keep_state else 1
         fast_ms = 2 * 8 * nbytes / (0.93 * 6.29e12) * 1e3
         losers, all_times, report_rounds = [], [], 0
+        best = pool[:8]                           # what the grid uses if nothing better is found
         while True:
             report_rounds += 1
             ptrs = (C.c_void_p * len(pool))(*[v.ptr for v in pool])
@@ -210,7 +211,12 @@ class BlockGrid:
                 else:
                     check(params.fn("choose_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes,
                                                         tries, 0.01, C.byref(picks), times, C.byref(done)))
-            except _lib.SolverException:          # e.g. no room for the 4 transient vectors: nothing was moved
+            except _lib.SolverException:          # e.g. no room for the 4 transient vectors: nothing was moved in THIS round
+                # pool[:8] is the assignment this round started from — the grid's own vectors in round 1, the best of the
+                # previous rounds afterwards (the grid's original vectors may then be among the losers): install it before
+                # anything is freed, so that the grid never points at a released vector
+                for k, f in enumerate(STATE_VARS):
+                    self.data[f], self.alt[f] = best[k], best[4 + k]
                 for v in pool[8:] + losers:
                     v.free()
                 return None
@@ -309,7 +315,9 @@ def tune_staged_placement(params, grid, min_bytes=None):
     nbytes = grid.data["rho"].nbytes
     if min_bytes is None:
         min_bytes = getattr(params, "placement_min_bytes", 256 << 20)
-    if tries <= 1 or nbytes < min_bytes or params.use_MPI:
+    # a tile with a remote side (an MPI rank, or a tile of an in-process group: use_MPI is False there and grid.comm is
+    # None) cannot run the timing cycle below on its own — its ghost exchange needs the neighbours
+    if tries <= 1 or nbytes < min_bytes or params.use_MPI or any(n != PROC_NULL for n in params.neighbours.values()):
         return None
     dev = params.device
     vectors = [grid.data[f] for f in FIELDS]

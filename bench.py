@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--grid", default=None, metavar="PXxPY", help="process grid (default: 1x1, 2x1, 2x2, 4x2 for 1, 2, 4, 8 ranks)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the global grid stays --cells² (or --global) whatever the number of GPUs")
+    ap.add_argument("--require-native", action="store_true",
+                    help="N > 1: exit with status 3 (after printing the line) when the halos do not travel through the "
+                         "library's own RCCL exchange, i.e. when config.halo_exchange_downgraded is true")
     ap.add_argument("--config", type=int, choices=(2, 3, 4, 5), default=None,
                     help="BASELINE.json configs[N-1]: 2 = Sod 8192² Godunov, 3 = Sedov 16384², "
                          "4 = Sod 32768x16384 on 2x2, 5 = Bizarrium 32768² on 4x2")
@@ -264,7 +267,13 @@ def main():
     # machine against (3) before anything is timed: five cycles from the same initial state must give the same dt
     # sequence and the same global mass / energy bit for bit on every rank; the first that does is used and named.
     halo_mode = None
+    # A transport downgrade must be LOUD (it would cost the multi-GPU target without failing anything): the line carries
+    # halo_exchange_downgraded (true when N > 1 over RCCL and anything but the library's native exchange is timed) and
+    # halo_exchange_error (every exception text and self-check miss on the way); --require-native turns it into exit 3.
+    halo_downgraded, halo_errors = False, []
     if dist is not None and grid.comm is not None:
+        if dist.get_backend() == "nccl" and not getattr(grid.comm, "native", False):
+            halo_errors.append("native exchange not initialised: " + str(getattr(params, "native_halo_error", "unknown reason")))
         from armon_amd.halo_exchange import HaloExchanger, allreduce_min
         from armon_amd.solver import conservation_vars, drain_halo
         native_comm = grid.comm if getattr(grid.comm, "native", False) else None
@@ -300,9 +309,12 @@ def main():
             for name, comm, so in candidates:
                 try:
                     same = 1.0 if probe(comm, so) == ref else 0.0
+                    if same == 0.0:
+                        halo_errors.append(f"{name.split(' ')[0]}: self-check against the host-synchronised protocol FAILED on rank {rank}")
                 except Exception as e:          # a transport that cannot run here must not cost the bench line
                     same = 0.0
                     failed.append(f"{name.split(' ')[0]}: {type(e).__name__}")
+                    halo_errors.append(f"{name.split(' ')[0]}: {type(e).__name__}: {str(e)[:300]}")
                 if allreduce_min(params, same) == 1.0:
                     halo_mode, chosen = name + " — self-check against the host-synchronised protocol passed", (comm, so)
                     break
@@ -318,6 +330,9 @@ def main():
             init_test(params, grid, tune=False)
             gdt.reset()
             grid.dt_inflight.clear()
+
+    if dist is not None and dist.get_backend() == "nccl":
+        halo_downgraded = not getattr(grid.comm, "native", False)       # what is timed below is not the library's own exchange
 
     from armon_amd.solver import conservation_vars
     mass0, energy0 = conservation_vars(params, grid)         # self-check of the timed work, see below
@@ -433,7 +448,9 @@ def main():
                    "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local,
-                   "hbm_placement": placement, "device": params.device.name, "halo_exchange": halo_mode},
+                   "hbm_placement": placement, "device": params.device.name, "halo_exchange": halo_mode,
+                   "halo_exchange_downgraded": halo_downgraded,
+                   "halo_exchange_error": "; ".join(halo_errors) if halo_errors else None},
         "hbm_GBps_algorithmic_whole_job": round((32 if args.f32 else 64) * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,
         "self_check": self_check,
@@ -452,6 +469,10 @@ def main():
             if hasattr(comm, "close"):
                 comm.close()                   # the library's RCCL communicators, before the launcher's
         dist.destroy_process_group()
+    if halo_downgraded:
+        print(f"bench.py: HALO EXCHANGE DOWNGRADED on rank {rank}: {halo_mode}; {'; '.join(halo_errors)}", file=sys.stderr)
+        if args.require_native:
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -382,7 +382,21 @@ ARMON_API int armon_hip_mgpu_init(int px, int py, const int* device_ids, armon_m
 ARMON_API int armon_hip_mgpu_unique_id(void* id);
 ARMON_API int armon_hip_mgpu_init_rank(int px, int py, int rank, int device_id, void* stream, const void* id,
                                        armon_mgpu** group);
+/* armon_hip_mgpu_init_rank in two steps, for hosts that want to agree on readiness in between (bench.py does, over its
+ * launcher's group): _prepare_rank is everything LOCAL to the process (RCCL symbols, context, streams, scratch) and may
+ * fail on one rank alone; _connect is the collective ncclCommInitRank of the two communicators — every rank enters it, or
+ * none (a rank that skipped it after a local failure would leave the others blocked in it). */
+ARMON_API int armon_hip_mgpu_prepare_rank(int px, int py, int rank, int device_id, void* stream, armon_mgpu** group);
+ARMON_API int armon_hip_mgpu_connect(armon_mgpu* group, const void* id);
 ARMON_API int armon_hip_mgpu_destroy(armon_mgpu* group);
+/* Test aids for the TRANSPORT (no reference counterpart: the reference's process grid is never periodic, ref
+ * src/parameters.jl:432). _set_periodic: out-of-grid neighbours wrap around along that axis, so a 1 x 1 rank group is its
+ * own neighbour on every side and ONE GPU executes the real ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd of
+ * armon_hip_halo_exchange_start (call it before the first exchange; the caller's sweeps must then treat those sides as
+ * remote: bc_low = bc_high = 0). _force_peer_copy: an in-process group moves its faces (and the dt scalars) with
+ * hipMemcpyPeerAsync even when both tiles sit on the same device. */
+ARMON_API int armon_hip_mgpu_set_periodic(armon_mgpu* group, int periodic_x, int periodic_y);
+ARMON_API int armon_hip_mgpu_force_peer_copy(armon_mgpu* group, int on);
 /* Test aid: from now on, with probability 1/2 each, the group's stream operations (packs, transfers, unpacks, the edge
  * join, the dt reduction) are preceded by a busy-wait kernel of up to max_delay_us on their stream — timings a single
  * GPU never produces by itself; results must not change. 0 switches it off. seed 0 = default sequence. */

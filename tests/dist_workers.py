@@ -97,3 +97,78 @@ def gpu_solver_worker(rank, world, port, P, N_global, test, opts, out_dir, backe
              origin=np.array(params.N_origin), n=np.array(params.N),
              **{k: stats.data.real_view(v) for k, v in host.items()})
     dist.destroy_process_group()
+
+
+def rccl_periodic_worker(rank, world, port, mode, N, test, opts, out_dir):
+    """ONE rank over RCCL on a PERIODIC 1 x 1 process grid (test aid, armon_hip_mgpu_set_periodic): the rank is its own
+    neighbour on the periodic sides, so exchange_start really issues ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on
+    the transfer stream (multi_gpu.hip) — the call a multi-GPU run makes, with the one peer a single GPU has.
+    mode "index": the index-encoded exchange of ref test/mpi.jl:272-360, with wrapped expectations, also under injected
+    delays and with the dt all-reduce of the second communicator running beside the faces; mode "run": a whole solve."""
+    import ctypes as C
+    import numpy as np
+    dist = _init(rank, world, port, "nccl")
+    import torch  # noqa: F401
+    import armon_amd
+    from armon_amd.blocking import Axis, Side, sides_along
+    from armon_amd.halo_exchange import setup
+    from armon_amd.parameters import PROC_NULL
+    from armon_amd.solver import BlockGrid
+    periodic = tuple(opts.pop("periodic"))
+    if mode == "run":
+        params = armon_amd.ArmonParameters(test=test, N=N, use_MPI=True, P=(1, 1), periodic=periodic, device_id=0, silent=5,
+                                           return_data=True, **opts)
+        stats = armon_amd.armon(params)
+        assert getattr(stats.data.comm, "native", False), "the library's RCCL exchange was not selected"
+        host = stats.data.device_to_host(("rho", "u", "v", "E", "p"))
+        np.savez(os.path.join(out_dir, "tile0.npz"), cycles=stats.cycles, dt=stats.last_dt, time=stats.final_time,
+                 **{k: stats.data.real_view(v) for k, v in host.items()})
+        stats.data.comm.close()
+        dist.destroy_process_group()
+        return
+    params = armon_amd.ArmonParameters(test="Sod", N=N, use_MPI=True, P=(1, 1), periodic=periodic, device_id=0, silent=5, **opts)
+    grid = BlockGrid(params)
+    comm = setup(params, grid)
+    assert getattr(comm, "native", False), "the library's RCCL exchange was not selected"
+    g = params.nghost
+    nx, ny = params.N
+    names = ("rho", "u", "v", "E", "p", "c", "g")
+    jj, ii = np.mgrid[-g:ny + g, -g:nx + g]
+    inside_x, inside_y = (ii >= 0) & (ii < nx), (jj >= 0) & (jj < ny)
+    dtype = params.data_type
+    errors = []
+    for seed in (0, 1, 2, 3):                       # 0: no injected delay
+        comm.set_chaos(300 if seed else 0, seed)
+        for vi, k in enumerate(names):
+            a = np.full((ny + 2 * g, nx + 2 * g), -1.0, dtype=dtype)
+            a[inside_x & inside_y] = (vi * 1e5 + jj * nx + ii)[inside_x & inside_y]
+            grid.data[k].copy_from_host(a.ravel())
+        scalar = params.device.zeros(2, dtype)
+        scalar.copy_from_host(np.array([3.5 + seed, 0.], dtype=dtype))
+        for subset in (names[:4], names):
+            for axis in (Axis.X, Axis.Y):
+                h = comm.start(sides_along(axis), subset)
+                comm.allreduce_min_device_async(scalar)      # comm_red on the compute stream while comm_halo moves the faces
+                comm.finish(h)
+        params.wait()
+        if float(scalar.to_host()[0]) != 3.5 + seed:
+            errors.append(("allreduce", seed, float(scalar.to_host()[0])))
+        for vi, k in enumerate(names):
+            a = grid.data[k].to_host().reshape(ny + 2 * g, nx + 2 * g)
+            expected = np.full_like(a, -1.0)
+            enc = (vi * 1e5 + (jj % ny) * nx + (ii % nx)).astype(dtype)          # the opposite border's global indices
+            expected[inside_x & inside_y] = enc[inside_x & inside_y]
+            for side, mask in ((Side.Left, inside_y & (ii < 0)), (Side.Right, inside_y & (ii >= nx)),
+                               (Side.Bottom, inside_x & (jj < 0)), (Side.Top, inside_x & (jj >= ny))):
+                if params.neighbours[side] != PROC_NULL:
+                    expected[mask] = enc[mask]
+            if not np.array_equal(a, expected):
+                errors.append((k, seed, int((a != expected).sum())))
+        sums = comm.allreduce_host([1.0, 2.0], "sum")
+        if sums != [1.0, 2.0]:
+            errors.append(("allreduce_host", sums))
+    with open(os.path.join(out_dir, "rank0.txt"), "w") as f:
+        f.write("OK\n" if not errors else f"FAIL {errors[:8]}\n")
+        f.write(f"{sorted((int(s), n) for s, n in params.neighbours.items())}\n")
+    comm.close()
+    dist.destroy_process_group()
