@@ -198,6 +198,28 @@ def lib():
     return _lib
 
 
+ALT_LIB_PATH = os.path.join(_HERE, "libarmon_hip_alt.so")
+_alt = None
+
+
+class alt_kernels:
+    """Context manager for the tests and tools that exercise the measured-and-rejected kernel forms (x_kernel 2 / 3,
+    armon_hip_cycle_xy): inside it every call of this package goes to libarmon_hip_alt.so — the same sources built with
+    -DARMON_ALT_KERNELS. Objects that hold a context (devices, grids, tile groups) must be created AND released inside."""
+
+    def __enter__(self):
+        global _lib, _alt
+        if _alt is None:
+            _alt = load_at(ALT_LIB_PATH)
+        self._saved, _lib = _lib, _alt
+        return _alt
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
 def check(rc):
     """Turn a non-zero status into SolverException(:cpp, msg) (ref ext/ArmonKokkos.jl:72-76)."""
     if rc != 0:

@@ -10,6 +10,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libarmon_hip.so")
+# A/B build: the product library + the measured-and-rejected kernel forms (-DARMON_ALT_KERNELS: whole-cycle kernels, LDS X
+# march, one-cell-per-lane DPP sweep). Only the tests and tools that exercise those forms load it.
+OUT_ALT = os.path.join(HERE, "libarmon_hip_alt.so")
+ALT_SOURCES = ("fused_sweep_f64.hip", "fused_sweep_f32.hip")     # the translation units the define changes
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: the "exact" kernels must evaluate one IEEE op per source op (bit parity with the
@@ -36,8 +40,8 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    objs, jobs = [], []
+def build(force=False, verbose=False, alt=True):
+    objs, objs_alt, jobs = [], [], []
     hdrs = headers()
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in sources():
@@ -45,6 +49,12 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + hdrs + [__file__]):
             jobs.append([HIPCC, *CXXFLAGS, "-c", os.path.join(CSRC, src), "-o", obj])
+        if alt and src in ALT_SOURCES:
+            obj_alt = os.path.join(HERE, "build", src[:-4] + "_alt.o")
+            if force or _stale(obj_alt, [os.path.join(CSRC, src)] + hdrs + [__file__]):
+                jobs.append([HIPCC, *CXXFLAGS, "-DARMON_ALT_KERNELS", "-c", os.path.join(CSRC, src), "-o", obj_alt])
+            obj = obj_alt
+        objs_alt.append(obj)
 
     def run(cmd):
         if verbose:
@@ -57,11 +67,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(OUT, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs,
-             "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+    for out, group in ((OUT, objs),) + (((OUT_ALT, objs_alt),) if alt else ()):
+        if jobs or force or _stale(out, group):
+            run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *group,
+                 "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
     return OUT
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, alt="--no-alt" not in sys.argv))

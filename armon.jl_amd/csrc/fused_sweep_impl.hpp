@@ -667,6 +667,12 @@ k_sweep_x_dpp(sweep_args a, int niter)
     sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK>(a, niter);
 }
 
+// =====================================================================================================================
+// Measured-and-rejected alternatives: the whole-cycle kernels k_cycle_xy / k_cycle_pc, the
+// LDS-transposed X march k_sweep_x_lds (and, in launch(), the one-cell-per-lane form of the DPP sweep). They are correct and
+// tested but 1.3-4x slower than what the solver runs, so they are only compiled with -DARMON_ALT_KERNELS, into
+// libarmon_hip_alt.so (build.py), which the tests and tools that exercise them load; the product library carries none.
+#ifdef ARMON_ALT_KERNELS
 // ---- whole cycle X then Y in ONE pass over memory (Sequential splitting) -----------------------------------------
 // A wave owns 64 consecutive columns (56 produced + the X sweep's 4-cell halo on both sides) and marches down y:
 // each step loads one row segment, sweeps it along x in place (lanes along x, DPP shifts: SpatialSweep<K = 1>) and
@@ -1029,6 +1035,8 @@ k_sweep_x_lds(sweep_args a)
     if (TRACK) cfl_block_store<1>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
 
+#endif  // ARMON_ALT_KERNELS
+
 // ---- launch ----------------------------------------------------------------------------------------------
 template <class PIPE, bool TRACK>
 int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
@@ -1050,7 +1058,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
         return check_launch("sweep_y");
     }
-#ifndef ARMON_ONLY_HEADLINE
+#if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
     if (a.x_kernel == 2) {
         dim3 grid((unsigned)((n_out + a.seg - 1) / a.seg), (unsigned)((a.ny + kXRows - 1) / kXRows));
         *n_blocks = (int64_t)grid.x * grid.y;
@@ -1065,7 +1073,7 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
     dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
     *n_blocks = (int64_t)grid.x * grid.y * kXSRows;          // one pair of maxima per wave
-#ifndef ARMON_ONLY_HEADLINE
+#if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
     if (k1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
                            grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
@@ -1109,7 +1117,11 @@ int y_run_length(int n_cu, int64_t nx, int64_t ny, int lag)
 int64_t max_blocks(const sweep_args& a)
 {
     const int64_t by = (a.nx + 16 + kYBlock - 1) / kYBlock * ((a.ny + a.seg - 1) / a.seg);
+#ifdef ARMON_ALT_KERNELS
     const int64_t bx_lds = (a.nx + a.seg - 1) / a.seg * ((a.ny + kXRows - 1) / kXRows);
+#else
+    const int64_t bx_lds = 0;
+#endif
     const int64_t bx_dpp = ((a.nx + 8) / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows) * kXSRows;     // per wave; niter >= 1, K = 1, LAG = 4
     int64_t m = by > bx_lds ? by : bx_lds;
     m = m > bx_dpp ? m : bx_dpp;
@@ -1169,7 +1181,12 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
                   "NULL state array");
     ARMON_REQUIRE(d->rho_in != d->rho_out && d->u_in != d->u_out && d->v_in != d->v_out && d->E_in != d->E_out,
                   "in and out arrays must not alias (ping-pong)");
+#ifdef ARMON_ALT_KERNELS
     ARMON_REQUIRE(d->x_kernel == 0 || d->x_kernel == 2 || d->x_kernel == 3, "unknown x_kernel form %d", d->x_kernel);
+#else
+    ARMON_REQUIRE(d->x_kernel == 0, "x_kernel form %d is a measured alternative: only libarmon_hip_alt.so (-DARMON_ALT_KERNELS) carries it",
+                  d->x_kernel);
+#endif
     const bool exact = d->exact != 0;
     const bool track = d->dt_cfl_out != nullptr;
     ARMON_REQUIRE(!track || (d->cfl_dx > 0 && d->cfl_dy > 0), "dt_cfl_out needs cfl_dx, cfl_dy > 0");
@@ -1434,7 +1451,16 @@ extern "C" int ARMON_CHOOSE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x_desc, c
 }
 
 // ---- whole cycle (X sweep then Y sweep, Sequential splitting) in one launch: k_cycle_xy --------------------------------
-#ifdef ARMON_CYCLE_FN
+#if defined(ARMON_CYCLE_FN) && !defined(ARMON_ALT_KERNELS)
+extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const ARMON_SWEEP_DESC* y)
+{
+    ARMON_REQUIRE(ctx && x && y, "NULL argument");
+    ARMON_REQUIRE(false, "the whole-cycle kernel is a measured alternative (slower than the two sweeps, DESIGN.md section 4.2): "
+                         "only libarmon_hip_alt.so (-DARMON_ALT_KERNELS) carries it");
+    return ARMON_ERR_INVALID_ARG;
+}
+#endif
+#if defined(ARMON_CYCLE_FN) && defined(ARMON_ALT_KERNELS)
 extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const ARMON_SWEEP_DESC* y)
 {
     ARMON_REQUIRE(ctx && x && y, "NULL argument");

@@ -78,6 +78,56 @@ def write_sub_domain_file(params, grid, file_name, no_msg=False, vars=SAVED_VARS
     return path
 
 
+def write_slices_files(params, grid, file_name, vars=SAVED_VARS):
+    """``write_slices=true`` (ref src/parameters.jl:229-232, call at src/solver.jl:508): "all saved_vars() to 3 output
+    files, one for the middle X row, another for the middle Y column, and another for the diagonal; with write_ghosts the
+    ghost cells too". The reference calls ``write_slices_files`` but does not define it anywhere in src/, so the file
+    names are this backend's: ``<file>_X`` (the row j = Ny÷2), ``<file>_Y`` (the column i = Nx÷2), ``<file>_diag`` (cells
+    (k, k), k < min(Nx, Ny)), each in the cell format of ``write_blocks_to_file``. Single block only (a tile writes the
+    slices of its own sub-domain, with the sub-domain suffix of ``build_file_path``)."""
+    fmt = ", ".join([_fmt(params.output_precision)] * len(vars)) + "\n"
+    sx = params.N[0] + 2 * params.nghost
+    g = params.nghost
+    (x0, x1), (y0, y1) = _rows(params, params.write_ghosts)
+    host = grid.device_to_host(vars)
+    cols = [np.asarray(host[v]).reshape(-1, sx) for v in vars]
+    jm, im = g + params.N[1] // 2, g + params.N[0] // 2
+    n_diag = min(x1 - x0, y1 - y0)
+    picks = {"X": [(jm, i) for i in range(x0, x1)], "Y": [(j, im) for j in range(y0, y1)],
+             "diag": [(y0 + k, x0 + k) for k in range(n_diag)]}
+    paths = []
+    for tag, cells in picks.items():
+        path = build_file_path(params, f"{file_name}_{tag}")
+        with open(path, "w") as f:
+            f.write("".join(fmt % tuple(c[j, i] for c in cols) for j, i in cells))
+        paths.append(path)
+    if params.is_root and params.silent < 2:
+        print(f"\nWrote slices to {', '.join(paths)}")
+    return paths
+
+
+def prepare_animation_dir(params):
+    """ref src/solver.jl:436-442: the root empties (or creates) the ``anim`` directory before the run."""
+    if params.animation_step == 0 or not params.is_root:
+        return
+    d = os.path.join(params.output_dir, "anim")
+    if os.path.isdir(d):
+        for name in os.listdir(d):
+            os.remove(os.path.join(d, name))
+    else:
+        os.makedirs(d)
+
+
+def write_animation_frame(params, grid):
+    """ref src/solver.jl:373-378, called after ``next_cycle!``: every ``animation_step`` cycles the saved_vars go to
+    ``anim/<output_file>_<frame:03d>`` as with write_output."""
+    cycle = grid.global_dt.cycle
+    if params.animation_step == 0 or (cycle - 1) % params.animation_step != 0:
+        return None
+    frame = (cycle - 1) // params.animation_step
+    return write_sub_domain_file(params, grid, os.path.join("anim", params.output_file) + f"_{frame:03d}", no_msg=True)
+
+
 def read_sub_domain_file(params, file_name, vars=SAVED_VARS):
     """Returns dict name → flat ghosted array (cells not in the file are NaN)."""
     n = params.block_size.n_cells

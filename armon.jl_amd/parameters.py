@@ -179,7 +179,11 @@ class ArmonParameters:
             solver_error("config", "async_cycle (CPU thread state machine) is replaced by HIP streams here")
         self.use_threading, self.use_simd = use_threading, use_simd
         self.use_cache_blocking, self.async_cycle = False, False
-        self.use_two_step_reduction = use_two_step_reduction
+        # ref src/reductions.jl:70-78,276-284: "two steps" = per-cell values into a temporary array, then a plain reduce of
+        # it, for GPU backends whose one-step mapreduce misbehaves. Every reduction of this backend already IS two-step
+        # (one partial per workgroup, then a fold kernel; reductions.hip) and deterministic, so both settings select the
+        # same, compliant behaviour: the option is satisfied, not dropped.
+        self.use_two_step_reduction = bool(use_two_step_reduction)
         self.kernel_block_size = block_size
         return options
 
@@ -216,6 +220,10 @@ class ArmonParameters:
         self.silent = silent
         self.output_dir, self.output_file = output_dir, output_file
         self.write_output, self.write_ghosts = write_output, write_ghosts
+        self.write_slices = bool(write_slices)          # 3 more files at the end of armon(): io.write_slices_files
+        self.animation_step = int(animation_step)       # a frame every `animation_step` cycles: solver.time_loop
+        if self.animation_step < 0:
+            solver_error("config", f"animation_step must be >= 0, got {animation_step}")
         self.output_precision = 17 if output_precision is None else int(output_precision)
         self.check_result = check_result
         self.return_data = return_data
@@ -291,7 +299,8 @@ class ArmonParameters:
     def fn(self, name):
         """The C-ABI entry point ``armon_hip_<name>`` for this run's data_type (``_f32`` suffix for Float32)."""
         from . import _lib
-        return getattr(_lib.lib(), "armon_hip_" + name + self.suffix)
+        L = self._device._L if self._device is not None else _lib.lib()      # the library this run's context came from
+        return getattr(L, "armon_hip_" + name + self.suffix)
 
     def cell_size(self, i_ax):
         """Global cell size along an axis, computed in T (ref src/solver_state.jl:341, src/reductions.jl:92)."""

@@ -729,9 +729,16 @@ def time_loop(params, grid):
             # the cycle's dt is only known after next_time_step on cycle 0: be conservative there
             ends = (gdt.cycle + 1 >= params.maxcycle or gdt.current_dt == 0
                     or params.T(gdt.time + gdt.current_dt) >= maxtime)
-        if solver_cycle(params, grid, last_cycle=ends):
+        # animation frames (ref :373-378) are written after next_cycle! when (cycle - 1) % animation_step == 0; the fused
+        # path only materialises p (a saved var) on request, so a cycle that ends with a frame asks for it like the last one
+        frame_due = params.animation_step != 0 and gdt.cycle % params.animation_step == 0
+        if solver_cycle(params, grid, last_cycle=ends or frame_due):
             break
         gdt.next_cycle()
+        if frame_due:
+            from .io import write_animation_frame
+            params.wait()
+            write_animation_frame(params, grid)
         if params.silent <= 1:
             params.wait()
             mass, energy = conservation_vars(params, grid)
@@ -760,6 +767,9 @@ def armon(params):
     """ref src/solver.jl:411-516 — main entry point, returns SolverStats."""
     if params.is_root and params.silent < 3:
         print(params)
+    if params.animation_step != 0:
+        from .io import prepare_animation_dir
+        prepare_animation_dir(params)
     grid = BlockGrid(params)
     if params.use_MPI:
         from .halo_exchange import setup
@@ -778,6 +788,9 @@ def armon(params):
     if params.write_output:
         from .io import write_sub_domain_file
         write_sub_domain_file(params, grid, params.output_file)
+    if params.write_slices:
+        from .io import write_slices_files
+        write_slices_files(params, grid, params.output_file)
     stats = SolverStats(final_time, dt, cycles, solve_time / 1e9, params.N[0] * params.N[1], cells_per_ns)
     if params.return_data:
         stats.data = grid

@@ -157,7 +157,7 @@ def cpu_baseline(test, scheme, target_seconds=12.0):
     value = n * n * 2 * run.cycles / run.solve_seconds / 1e6
     return {"value": round(value, 2), "unit": "Mcells/s per sweep", "cores": cores, "kind": "port",
             "sample": f"{test} {n}x{n} fp64 {scheme}+minmod+euler_2nd, {run.cycles} cycles "
-                      f"({run.solve_seconds:.1f} s), oracle/armon_oracle.c -O2 -march=native OpenMP"}
+                      f"({run.solve_seconds:.1f} s), oracle/armon_oracle.c -O3 -march=native -ffp-contract=off OpenMP (oracle/Makefile)"}
 
 
 def main():

@@ -267,9 +267,10 @@ typedef struct {
     int32_t bc_low, bc_high; /* 1: physical boundary on the low/high side of `axis` → mirror BC
                                 applied in-tile; 0: ghosts already hold neighbour data (halo)   */
     int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to staged  */
-    int32_t x_kernel;        /* X-sweep kernel form, for tests/tuning: 0 default (lanes along x, DPP
-                                shifts, 2 cells per lane), 3 same with 1 cell per lane, 2 LDS-transposed
-                                march                                                            */
+    int32_t x_kernel;        /* X-sweep kernel form: 0 = the one the library runs (lanes along x, DPP
+                                shifts, 2 cells per lane). 3 (1 cell per lane) and 2 (LDS-transposed
+                                march) are measured alternatives that exist only in the A/B build
+                                libarmon_hip_alt.so (-DARMON_ALT_KERNELS); the product library refuses them */
     int64_t nx, ny;          /* real cells of the block                                         */
     double  dt, dx;          /* sweep time step (current_dt·factor) and cell size along axis    */
     double  gamma;           /* perfect gas only                                                */
@@ -305,7 +306,9 @@ ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
  * fp64, GAD + minmod + euler_2nd, perfect gas, tuned arithmetic only; a block whose Y sides are remote cannot use it
  * (the rows received from a neighbour would have to be X-swept first). x_desc->x_kernel selects the form: 0 = one wave
  * runs both stages, 4 = producer / consumer waves through LDS. Both are measured alternatives (register-bound, slower
- * than the two launches today: DESIGN.md section 4.2), not what the solver runs. No reference counterpart. */
+ * than the two launches today: DESIGN.md section 4.2), not what the solver runs: the kernels are compiled only into the
+ * A/B build libarmon_hip_alt.so (-DARMON_ALT_KERNELS); in the product library this entry point returns
+ * ARMON_ERR_INVALID_ARG. No reference counterpart. */
 ARMON_API int armon_hip_cycle_xy(armon_ctx*, const armon_sweep_desc* x_desc, const armon_sweep_desc* y_desc);
 
 /* Placement of the 8 vectors a fused sweep streams (4 read + 4 written). On MI355X the same sweeps run 10-20 %

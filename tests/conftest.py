@@ -15,8 +15,8 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The tests load armon.jl_amd/libarmon_hip.so (built in-tree, git-ignored): build it when it is missing and
     hipcc is there (≈3 min; cross-compiles without a GPU). There is no CPU stand-in to fall back to."""
-    lib = os.path.join(ROOT, "armon.jl_amd", "libarmon_hip.so")
-    if not os.path.exists(lib) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+    libs = [os.path.join(ROOT, "armon.jl_amd", name) for name in ("libarmon_hip.so", "libarmon_hip_alt.so")]
+    if not all(os.path.exists(p) for p in libs) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         import importlib.util
         spec = importlib.util.spec_from_file_location("armon_build", os.path.join(ROOT, "armon.jl_amd", "build.py"))
         mod = importlib.util.module_from_spec(spec)

@@ -225,11 +225,14 @@ def test_fast_arithmetic_golden_and_conservation(test):
     ("Bizarrium", (64, 32), dict(maxcycle=12, scheme="Godunov")),
 ])
 def test_alternative_x_kernels(oracle, test, N, opts, xk, exact):
+    """The measured-and-rejected X forms live in the A/B build only (libarmon_hip_alt.so, -DARMON_ALT_KERNELS)."""
     import armon_amd
-    params = armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True, exact_arithmetic=exact, **opts)
-    params.x_kernel = xk
-    stats = armon_amd.armon(params)
-    host = stats.data.device_to_host()
+    from armon_amd import _lib
+    with _lib.alt_kernels():
+        params = armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True, exact_arithmetic=exact, **opts)
+        params.x_kernel = xk
+        stats = armon_amd.armon(params)
+        host = stats.data.device_to_host()
     orun, f = oracle.solve(test=test, N=N, **opts)
     assert stats.cycles == orun.cycles
     for k in ("rho", "u", "v", "E", "p"):
@@ -390,7 +393,16 @@ def test_whole_cycle_kernel_equals_the_two_sweeps(test, N):
     from armon_amd import _lib
     from armon_amd.blocking import Axis
     from armon_amd.solver import STATE_VARS, BlockGrid, init_test, local_time_step, sweep_desc, update_EOS
-    L = _lib.lib()
+    with _lib.alt_kernels() as L:        # the whole-cycle kernels live in the A/B build only (libarmon_hip_alt.so)
+        _whole_cycle_check(L, test, N)
+
+
+def _whole_cycle_check(L, test, N):
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.blocking import Axis
+    from armon_amd.solver import STATE_VARS, BlockGrid, init_test, local_time_step, sweep_desc, update_EOS
     params = armon_amd.ArmonParameters(test=test, N=N, silent=5, maxcycle=10)
     grid = BlockGrid(params)
     init_test(params, grid)
@@ -422,6 +434,26 @@ def test_whole_cycle_kernel_equals_the_two_sweeps(test, N):
     d_y = sweep_desc(params, grid, Axis.Y, dt, dy)
     d_x.exact = d_y.exact = 1
     assert L.armon_hip_cycle_xy(dev.ctx, C.byref(d_x), C.byref(d_y)) != 0
+
+
+def test_product_library_refuses_the_alternative_kernels():
+    """libarmon_hip.so carries only what the solver runs: the rejected forms answer with an error, not with a kernel."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.blocking import Axis
+    from armon_amd.solver import BlockGrid, init_test, sweep_desc
+    params = armon_amd.ArmonParameters(test="Sod", N=(64, 32), silent=5)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    L = _lib.lib()
+    d_x = sweep_desc(params, grid, Axis.X, 1e-4, params.cell_size(0))
+    d_y = sweep_desc(params, grid, Axis.Y, 1e-4, params.cell_size(1))
+    assert L.armon_hip_cycle_xy(params.device.ctx, C.byref(d_x), C.byref(d_y)) == 1
+    assert b"libarmon_hip_alt.so" in L.armon_hip_last_error()
+    for xk in (2, 3):
+        d_x.x_kernel = xk
+        assert L.armon_hip_sweep(params.device.ctx, C.byref(d_x)) == 1 and b"libarmon_hip_alt.so" in L.armon_hip_last_error()
 
 
 # ---- parity gaps named by the round-2 review ------------------------------------------------------------------------
@@ -567,3 +599,34 @@ def test_invalid_time_step_is_reported_by_a_tile_group(force_peer):
         assert e.value.category == "time" and gdt.cycle <= 3
     finally:
         group.close()
+
+
+@pytest.mark.parametrize("fused", MODES)
+def test_animation_frames_and_slices(tmp_path, fused):
+    """animation_step (ref src/solver.jl:373-378: a frame after next_cycle! whenever (cycle - 1) % step == 0, in
+    anim/<output_file>_<frame:03d>, the directory emptied first, :436-442) and write_slices (ref src/parameters.jl:229-232:
+    middle X row, middle Y column, diagonal). A frame written after cycle c equals the output of a run that stops at c."""
+    import os
+    import armon_amd
+    from armon_amd import io as aio
+    N = (40, 28)
+    common = dict(test="Sod_circ", N=N, silent=5, use_fused_sweep=fused, exact_arithmetic=True, output_dir=str(tmp_path))
+    os.makedirs(tmp_path / "anim")
+    (tmp_path / "anim" / "stale_000").write_text("left over from an earlier run\n")
+    params = armon_amd.ArmonParameters(maxcycle=8, animation_step=3, write_slices=True, write_output=True, output_file="run",
+                                       **common)
+    armon_amd.armon(params)
+    assert sorted(os.listdir(tmp_path / "anim")) == ["run_000", "run_001", "run_002"]
+    for frame, cycle in ((0, 1), (1, 4), (2, 7)):
+        p2 = armon_amd.ArmonParameters(maxcycle=cycle, write_output=True, output_file=f"stop{cycle}", **common)
+        armon_amd.armon(p2)
+        a = aio.read_sub_domain_file(params, os.path.join("anim", f"run_{frame:03d}"))
+        b = aio.read_sub_domain_file(p2, f"stop{cycle}")
+        for k in aio.SAVED_VARS:
+            assert np.array_equal(a[k], b[k], equal_nan=True), (frame, k)
+    full = aio.read_sub_domain_file(params, "run")
+    g, sx = params.nghost, N[0] + 2 * params.nghost
+    cols = np.stack([np.asarray(full[k]).reshape(-1, sx)[g:g + N[1], g:g + N[0]] for k in aio.SAVED_VARS], axis=-1)
+    load = lambda tag: np.array([[float(t) for t in line.split(",")] for line in open(tmp_path / f"run_{tag}")])
+    assert np.array_equal(load("X"), cols[N[1] // 2]) and np.array_equal(load("Y"), cols[:, N[0] // 2])
+    assert np.array_equal(load("diag"), np.array([cols[k, k] for k in range(min(N))]))

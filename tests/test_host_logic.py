@@ -26,9 +26,11 @@ def test_library_exports_every_symbol_of_the_header():
     import ctypes
     syms = declared_symbols()
     assert len(syms) >= 34
-    L = ctypes.CDLL(armon_amd.LIB_PATH)
-    for s in syms:
-        assert hasattr(L, s), f"{s} declared in include/armon_hip.h but not exported"
+    from armon_amd._lib import ALT_LIB_PATH
+    for path in (armon_amd.LIB_PATH, ALT_LIB_PATH):      # the product library and the A/B build with the alternative kernels
+        L = ctypes.CDLL(path)
+        for s in syms:
+            assert hasattr(L, s), f"{s} declared in include/armon_hip.h but not exported by {path}"
     # and the ctypes binding table covers exactly the same set
     from armon_amd._lib import SIGNATURES
     assert sorted(SIGNATURES) == syms

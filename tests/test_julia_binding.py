@@ -253,3 +253,125 @@ def test_julia_file_is_structurally_sound():
                  "halo_exchange_start!", "halo_exchange_finish!", "halo_exchange_finish_edge!", "edge_context", "edge_dt",
                  "edge_join!", "dt_allreduce!", "TileGroup", "HaloDesc", "check", "fn"):
         assert name in defined, f"{name} is called but never defined"
+
+
+# ---- names the binding takes from the reference (fixture made from /root/reference by tests/golden/make_julia_names.py) ----
+import json
+
+NAMES = json.load(open(os.path.join(ROOT, "tests", "golden", "julia_names.json"), encoding="utf-8"))
+SRC = _strip_julia(JL)
+IDENT = r"[^\W\d][\w!]*"
+
+
+def _known(name):
+    return name in NAMES["functions"] or name in NAMES["types"]
+
+
+def test_every_imported_name_exists_in_the_reference():
+    """`import Armon: a, b, …` fails at load time for a name Armon does not define: every imported name, and every
+    qualified `Armon.X` the file uses, must be a function, type or enum module of the reference's sources."""
+    imported = []
+    for m in re.finditer(r"^import Armon:(.*(?:\n[ \t]+.*)*)", SRC, re.M):
+        imported += [n.strip() for n in m.group(1).replace("\n", " ").split(",") if n.strip()]
+    assert len(imported) >= 40
+    missing = [n for n in imported if not _known(n)]
+    assert not missing, f"imported from Armon but not defined there: {missing}"
+    qualified = sorted(set(re.findall(r"\bArmon\.(" + IDENT + r")", SRC)))
+    assert len(qualified) >= 15
+    missing = [n for n in qualified if not _known(n)]
+    assert not missing, f"Armon.X used but not defined in the reference: {missing}"
+
+
+# which reference struct a variable name of the binding stands for (by the file's own conventions)
+VAR_TYPES = {"p": "ArmonParameters", "params": "ArmonParameters", "state": "SolverState", "gdt": "GlobalTimeStep",
+             "d": "BlockData", "blk": "LocalTaskBlock", "grid": "BlockGrid"}
+SECOND_LEVEL = {("state", "steps_ranges"): "StepsRanges", ("blk", "state"): "SolverState"}
+
+
+def test_every_field_the_binding_reads_exists_in_the_reference_struct():
+    """state.riemann_scheme, p.cart_coords, gdt.current_dt, d.uˢ, blk.size …: a misspelt field is a runtime error in Julia."""
+    seen = 0
+    for m in re.finditer(r"(?<![\w.])(" + "|".join(VAR_TYPES) + r")\.(" + IDENT + r")(?:\.(" + IDENT + r"))?", SRC):
+        var, field, sub = m.groups()
+        line = SRC.count("\n", 0, m.start()) + 1
+        assert field in NAMES["fields"][VAR_TYPES[var]], f"line {line}: {var}.{field} — {VAR_TYPES[var]} has no such field"
+        seen += 1
+        if sub and (var, field) in SECOND_LEVEL:
+            t = SECOND_LEVEL[(var, field)]
+            assert sub in NAMES["fields"][t], f"line {line}: {var}.{field}.{sub} — {t} has no such field"
+    assert seen >= 60
+    # fields written by the binding must be fields too (p.backend_options = …, state.dt = …)
+    for var, field in re.findall(r"(?<![\w.])(params|state|gdt)\.(" + IDENT + r")\s*=(?!=)", SRC):
+        assert field in NAMES["fields"][VAR_TYPES[var]], (var, field)
+
+
+def _method_defs(name):
+    """positional parameter lists of the methods `name(...)` the binding defines (long and one-line form)"""
+    out = []
+    for m in re.finditer(r"(?:^|\n)\s*(?:function\s+)?(?:Armon\.)?" + re.escape(name) + r"\(", SRC):
+        start = m.end() - 1
+        params = SRC[start + 1:matching(SRC, start)]
+        rest = SRC[matching(SRC, start) + 1:matching(SRC, start) + 120]
+        if not (m.group(0).lstrip().startswith("function") or re.match(r"\s*(?:where\s+[^=\n]+?)?\s*=(?!=)", rest)):
+            continue                                     # a call, not a definition
+        pos = split_top_sep(params, ";")[0] if params.strip() else ""
+        out.append([a for a in split_top(pos)] if pos.strip() else [])
+    return out
+
+
+def split_top_sep(s, sep):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == sep and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    out.append(cur)
+    return out
+
+
+@pytest.mark.parametrize("kernel", ["perfect_gas_EOS!", "bizarrium_EOS!", "acoustic!", "acoustic_GAD!", "cell_update!",
+                                    "advection_first_order!", "advection_second_order!", "euler_projection!",
+                                    "boundary_conditions!", "pack_to_array!", "unpack_from_array!", "init_test"])
+def test_kernel_overrides_have_the_generated_main_signature(kernel):
+    """Each kernel method of the binding replaces the MAIN function `@generic_kernel` generates —
+    K(params, [data,] range, rest...; kwargs), ref src/generic_kernel.jl:825-846 — so it must take exactly those positional
+    parameters (the reference's call sites pass them positionally) and accept the keyword arguments (`; kw...`)."""
+    sigs = NAMES["kernel_main_signatures"][kernel]
+    defs = _method_defs(kernel)
+    assert len(defs) == 1, (kernel, defs)
+    mine = defs[0]
+    want = sigs[0]
+    assert len(mine) == len(want), f"{kernel}: binding takes {mine}, the generated main function takes {want}"
+    assert re.match(r"p::HP\{T\}", mine[0].strip())
+    if "data" in want:
+        assert re.match(r"d::BlockData", mine[1].strip()), mine
+    assert re.search(r"::DomainRange", mine[want.index("range")]), mine
+    # the remaining parameters keep the reference's order: compare the names where the binding keeps them
+    rename = {"test_case": "test", "lim": "lim"}
+    for a, b in zip(mine[want.index("range") + 1:], want[want.index("range") + 1:]):
+        a = a.split("::")[0].strip()
+        assert a in (rename.get(b, b), b.rstrip("_")) or a.replace("advection_", "a") == b.replace("advection_", "a"), (kernel, a, b)
+    # keyword arguments of the generated function (no_threading, …) must be accepted
+    src = SRC[SRC.index(kernel + "(p::HP{T}"):]
+    assert re.match(re.escape(kernel) + r"\([^;]*;\s*kw\.\.\.\)", src.replace("\n", " ")), kernel
+
+
+@pytest.mark.parametrize("fname,arity", [("create_device", 1), ("init_backend", 2), ("device_array_type", 1),
+                                         ("host_array_type", 1), ("device_memory_info", 1), ("print_device_info", 3),
+                                         ("dtCFL_kernel", 4), ("conservation_vars", 2), ("solver_cycle", 2)])
+def test_hook_overrides_match_a_reference_method(fname, arity):
+    """The backend hooks and whole-step overrides extend functions of the reference: same name, and a positional arity the
+    reference itself defines for that function (ref src/parameters.jl:751-802,921-951; src/reductions.jl:65,271;
+    src/solver.jl:288)."""
+    assert fname in NAMES["functions"], fname
+    defs = _method_defs(fname)
+    assert defs, f"{fname} is not defined by the binding"
+    for d in defs:
+        assert len(d) == arity, (fname, d)
+    assert str(arity) in NAMES["functions"][fname], (fname, arity, NAMES["functions"][fname])

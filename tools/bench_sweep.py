@@ -30,6 +30,9 @@ ap.add_argument("--align", default="", help="comma list of ARMON_SWEEP_ALIGN val
 ap.add_argument("--xk", default="0", help="comma list of X kernel forms: 0 spatial K=2, 3 spatial K=1, 1 LDS vec, 2 LDS generic")
 args = ap.parse_args()
 ny = args.ny or args.n
+if args.xk != "0":       # forms 2 and 3 are compiled into the A/B build only (libarmon_hip_alt.so, -DARMON_ALT_KERNELS)
+    from armon_amd import _lib
+    _lib.alt_kernels().__enter__()
 
 params = armon_amd.ArmonParameters(test=args.test, N=(args.n, ny), scheme=args.scheme, projection=args.projection,
                                    silent=5, maxcycle=10)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole-cycle kernel (armon_hip_cycle_xy: X sweep + Y sweep in one pass) against the two fused sweeps: same bits,
-and the time of both forms.   ARMON_HIP_LIB=variants/cyc1/libarmon_hip.so python tools/cycle_probe.py"""
+and the time of both forms, from the A/B build libarmon_hip_alt.so.   python tools/cycle_probe.py"""
 import argparse
 import ctypes as C
 import os
@@ -19,7 +19,9 @@ ap.add_argument("--n", type=int, default=16384)
 ap.add_argument("--rounds", type=int, default=10)
 ap.add_argument("--seg", type=int, default=0)
 args = ap.parse_args()
-L = _lib.lib()
+# the whole-cycle kernels are compiled into the A/B build only (libarmon_hip_alt.so, -DARMON_ALT_KERNELS)
+_alt = _lib.alt_kernels()
+L = _alt.__enter__()
 
 
 def check_small(test, N):
