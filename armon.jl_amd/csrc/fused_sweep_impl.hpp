@@ -165,9 +165,14 @@ struct cfl_track {
     real au = 0, av = 0;
     __device__ __forceinline__ void add(real u, real v, real c)
     {
+#ifdef ARMON_CFL_PLAIN_MAX     // A/B builds (tools/build_variant.sh): the floating-point maxima of rounds 1-2, which drop a NaN
+        au = phys::mx(au, phys::abs_(phys::mx(phys::abs_(u + c), phys::abs_(u - c))));
+        av = phys::mx(av, phys::abs_(phys::mx(phys::abs_(v + c), phys::abs_(v - c))));
+#else
         // amax: unsigned maximum of the bit patterns — the same maximum for these non-negative values, and a NaN sticks
         au = phys::amax(au, phys::abs_(phys::mx(phys::abs_(u + c), phys::abs_(u - c))));
         av = phys::amax(av, phys::abs_(phys::mx(phys::abs_(v + c), phys::abs_(v - c))));
+#endif
     }
 };
 
@@ -1103,8 +1108,14 @@ int y_run_length(int n_cu, int64_t nx, int64_t ny, int lag)
         if (seg < 32) break;
         if ((ny + seg - 1) / seg != nruns) continue;                              // same launch as a smaller nruns
         const double rounds = (double)(cols * nruns) / slots;
-        if (rounds < 2.) continue;
-        const double cost = 0.5 * (rounds + std::ceil(rounds)) * (double)(seg + 2 * lag);
+        // One round that (nearly) fills every slot is the other good launch: every workgroup is resident from the start,
+        // the runs are as long as they can be. Small tiles need it — 4096 x 8192 (the tile of 16384² on 8 GPUs): 273 rows in
+        // 0.996 rounds 0.388 ms, 137 rows in 1.99 rounds 0.394, 92 rows in 2.99 rounds (the choice until round 3) 0.401,
+        // 512 rows in 0.53 rounds 0.590 (profiles/r03_ab_yseg_4096x8192.txt) — while at 16384² the only single round
+        // leaves 11 % of the slots empty and stays excluded (3.19 ms against 3.08).
+        const bool full_single_round = rounds <= 1. && rounds >= 0.93;
+        if (rounds < 2. && !full_single_round) continue;
+        const double cost = (full_single_round ? 1. : 0.5 * (rounds + std::ceil(rounds))) * (double)(seg + 2 * lag);
         if (cost < best_cost) {
             best_cost = cost;
             best = (int)seg;
