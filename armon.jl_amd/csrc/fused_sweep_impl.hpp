@@ -169,9 +169,17 @@ struct cfl_track {
         au = phys::mx(au, phys::abs_(phys::mx(phys::abs_(u + c), phys::abs_(u - c))));
         av = phys::mx(av, phys::abs_(phys::mx(phys::abs_(v + c), phys::abs_(v - c))));
 #else
-        // amax: unsigned maximum of the bit patterns — the same maximum for these non-negative values, and a NaN sticks
+        // max(|u + c|, |u - c|) = |u| + |c| — bit for bit, not only in exact arithmetic: the two candidates are fl(|u| + |c|)
+        // and |fl(|u| - |c|)| in some order, and rounding is monotone and symmetric. One addition instead of two, two
+        // absolute values and a select. amax: unsigned maximum of the bit patterns — the same maximum for these
+        // non-negative values, and a NaN sticks.
+#ifdef ARMON_CFL_TWO_SUMS      // A/B builds: the reference's expression as it stands
         au = phys::amax(au, phys::abs_(phys::mx(phys::abs_(u + c), phys::abs_(u - c))));
         av = phys::amax(av, phys::abs_(phys::mx(phys::abs_(v + c), phys::abs_(v - c))));
+#else
+        au = phys::amax(au, phys::abs_(u) + phys::abs_(c));
+        av = phys::amax(av, phys::abs_(v) + phys::abs_(c));
+#endif
 #endif
     }
 };
@@ -510,9 +518,14 @@ k_sweep_y2(sweep_args a)
 #define ARMON_XS_ROWS 4          // rows (= waves) per workgroup of the X sweep (tuning macro)
 #endif
 constexpr int kXSRows = ARMON_XS_ROWS;
-constexpr int kXSNiter = 2;      // strips per wave (A/B over 1..137 with tools/ab_sweep.py: short-lived waves keep the global access order sequential)
-
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
+// One strip per wave (SINGLE): load, sweep, store, exit — no second register set for a prefetched strip, 104-119 VGPRs, 4
+// waves per SIMD; the other waves of the SIMD hide the load. Rounds 1-2 ran TWO strips per wave with the second one's 32
+// input registers prefetched during the first (166-184 VGPRs, 2-3 waves per SIMD): A/B in one process
+// (profiles/r03_ab_x_single_strip.txt) tuned 2.875 -> 2.817 ms, tuned with dt tracking 3.240 -> 2.923 (2 -> 4 waves), exact
+// 3.444 -> 3.083, exact with tracking 3.818 -> 3.435, a 4096 x 8192 tile 0.415 -> 0.367. The multi-strip form stays in
+// the A/B build only (-DARMON_ALT_KERNELS, knob ARMON_XS_NITER > 1).
+constexpr int kXSNiter = 1;
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK, bool SINGLE>
 __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 {
     using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, K, real>;
@@ -551,7 +564,6 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 
     SW sw{a.dt, a.dx, a.gamma};
     cfl_track cfl;
-
     // Strip origins are aligned so that a strip's stores start on a 64-B sector of the ghosted row (for the
     // usual STRIDE = 120 = 15 sectors); the first strip of a row is then a short one (stores masked below o_lo).
     const int64_t w_first = a.x_first + (int64_t)vbx * niter * STRIDE;
@@ -598,7 +610,7 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     auto strip_exists = [&](int it) { return it < niter && w_first + (int64_t)it * STRIDE < a.o_hi; };
     auto do_strip = [&](auto slot, int it) {
         constexpr int B = decltype(slot)::value;
-        if (strip_exists(it + 1)) load_strip(std::integral_constant<int, 1 - B>{}, it + 1);
+        if (!SINGLE && strip_exists(it + 1)) load_strip(std::integral_constant<int, 1 - B>{}, it + 1);
         const int64_t w0 = w_first + (int64_t)it * STRIDE;    // first cell this strip produces
         const int64_t j0 = w0 - HALO + (int64_t)lane * K;
 
@@ -641,7 +653,12 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
             }
         }
     };
-    if (row_ok && strip_exists(0)) {
+    if (SINGLE) {
+        if (row_ok && strip_exists(0)) {
+            load_strip(std::integral_constant<int, 0>{}, 0);
+            do_strip(std::integral_constant<int, 0>{}, 0);
+        }
+    } else if (row_ok && strip_exists(0)) {
         load_strip(std::integral_constant<int, 0>{}, 0);
         for (int it = 0; strip_exists(it); it += 2) {
             do_strip(std::integral_constant<int, 0>{}, it);
@@ -665,11 +682,11 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 #ifndef ARMON_XS_WAVES
 #define ARMON_XS_WAVES 1         // minimum waves per SIMD the X sweep is compiled for (tuning macro; 3 = cap at 168 VGPRs)
 #endif
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK>
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK, bool SINGLE = true>
 __global__ void __launch_bounds__(64 * kXSRows, ARMON_XS_WAVES)
 k_sweep_x_dpp(sweep_args a, int niter)
 {
-    sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK>(a, niter);
+    sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK, SINGLE>(a, niter);
 }
 
 // =====================================================================================================================
@@ -1072,7 +1089,13 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         return check_launch("sweep_x_lds");
     }
 #endif
-    const int niter = ctx->tune_xs_niter > 0 ? ctx->tune_xs_niter : kXSNiter;
+    // one strip per wave; the A/B build also carries the multi-strip form with its prefetch buffer (ARMON_XS_NITER > 1)
+    int niter = 1;
+#if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
+    if (ctx->tune_xs_niter > 1) niter = ctx->tune_xs_niter;
+#elif defined(ARMON_XS_MULTI)      // tools/build_variant.sh: the round-2 form alone, for A/B timing
+    niter = ctx->tune_xs_niter > 0 ? ctx->tune_xs_niter : 2;
+#endif
     const bool k1 = a.x_kernel == 3;
     const int halo = k1 ? PIPE::LAG : 4;
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
@@ -1080,12 +1103,20 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     *n_blocks = (int64_t)grid.x * grid.y * kXSRows;          // one pair of maxima per wave
 #if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
     if (k1)
-        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK>),
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK, false>),
+                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+    else if (niter > 1)
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK, false>),
                            grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
     else
 #endif
-        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK>),
+#ifdef ARMON_XS_MULTI
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK, false>),
                            grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+#else
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK, true>),
+                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+#endif
     return check_launch("sweep_x_dpp");
 }
 

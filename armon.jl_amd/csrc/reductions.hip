@@ -28,22 +28,39 @@ __device__ __forceinline__ T block_reduce(T v, T* lds)
 // min over the cells of min(dx / a, dy / b), a = max(|u+c|, |u-c|), b = max(|v+c|, |v-c|). A correctly rounded division
 // is monotone in its divisor, so that minimum is min(dx / max a, dy / max b) — the same bits with two divisions per
 // LAUNCH instead of two per cell (the fused sweeps reduce their CFL step the same way, fused_sweep_impl.hpp).
+// Two cells per lane with 16-B loads (8-B for fp32) wherever a row of the range starts on such a boundary in all three arrays
+// (every row of an even-pitched block does), one cell per lane otherwise. max(|u + c|, |u - c|) is evaluated as |u| + |c|: the
+// same bits (the two candidates are fl(|u| + |c|) and |fl(|u| - |c|)| in some order; rounding is monotone and symmetric).
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 k_dtCFL_partial(armon_range r, const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ c,
                 T* __restrict__ partials)
 {
+    typedef T V2 __attribute__((ext_vector_type(2)));
     __shared__ T lds[kBlock / kWave];
     T au = T(0.), av = T(0.);
+    auto add = [&](T uu, T vv, T cc) {
+        // amax: a NaN in one cell sticks (the reference's reduction ends in `Invalid time step`, ref src/solver_state.jl:123)
+        au = phys::amax(au, phys::abs_(uu) + phys::abs_(cc));
+        av = phys::amax(av, phys::abs_(vv) + phys::abs_(cc));
+    };
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
         const int64_t base = r.col_start + j * r.col_step + r.row_start;
-        for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < r.row_len;
-             k += (int64_t)gridDim.x * blockDim.x) {
-            const int64_t i = base + k;
-            const T uu = u[i], vv = v[i], cc = c[i];
-            // amax: a NaN in one cell sticks (the reference's reduction ends in `Invalid time step`, ref src/solver_state.jl:123)
-            au = phys::amax(au, phys::abs_(phys::mx(phys::abs_(uu + cc), phys::abs_(uu - cc))));
-            av = phys::amax(av, phys::abs_(phys::mx(phys::abs_(vv + cc), phys::abs_(vv - cc))));
+        constexpr uintptr_t mask = 2 * sizeof(T) - 1;
+        const bool pairs = (((uintptr_t)(u + base) | (uintptr_t)(v + base) | (uintptr_t)(c + base)) & mask) == 0;   // uniform
+        if (pairs) {
+            const int64_t np = r.row_len >> 1;
+            for (int64_t k = tid; k < np; k += nthreads) {
+                const V2 uu = *reinterpret_cast<const V2*>(u + base + 2 * k);
+                const V2 vv = *reinterpret_cast<const V2*>(v + base + 2 * k);
+                const V2 cc = *reinterpret_cast<const V2*>(c + base + 2 * k);
+                add(uu.x, vv.x, cc.x);
+                add(uu.y, vv.y, cc.y);
+            }
+            if ((r.row_len & 1) && tid == 0) add(u[base + r.row_len - 1], v[base + r.row_len - 1], c[base + r.row_len - 1]);
+        } else {
+            for (int64_t k = tid; k < r.row_len; k += nthreads) add(u[base + k], v[base + k], c[base + k]);
         }
     }
     const T ru = block_reduce<op_max>(au, lds);
@@ -113,9 +130,9 @@ k_conservation_partial(armon_range r, const T* __restrict__ rho, const T* __rest
 
 // Grid for a reduction over a range: enough workgroups to fill the chip (≈8 per CU), never more than
 // the range needs; each workgroup strides over rows (y) and row chunks (x).
-inline void reduce_grid(const armon_ctx* ctx, const armon_range& r, dim3& grid)
+inline void reduce_grid(const armon_ctx* ctx, const armon_range& r, dim3& grid, int cells_per_thread = 1)
 {
-    int64_t gx = (r.row_len + kBlock - 1) / kBlock;
+    int64_t gx = (r.row_len + (int64_t)kBlock * cells_per_thread - 1) / ((int64_t)kBlock * cells_per_thread);
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     int64_t target = (int64_t)ctx->n_cu * 8;
@@ -138,7 +155,7 @@ int dtCFL_async_impl(armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, cons
     // the minimum over no cell is +inf (the reference's mapreduce has init = Inf, ref src/reductions.jl:79-87): an empty
     // range folds zero partials
     dim3 grid(1, 1, 1);
-    if (!range_empty(r)) reduce_grid(ctx, r, grid);
+    if (!range_empty(r)) reduce_grid(ctx, r, grid, 2);
     const int64_t n = range_empty(r) ? 0 : (int64_t)grid.x * grid.y;
     int rc = ensure_partials(ctx, (size_t)(n > 0 ? n : 1) * 2);
     if (rc != ARMON_OK) return rc;

@@ -221,6 +221,9 @@ def main():
     if world > 1 or os.environ.get("ARMON_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise RCCL init/all-reduce with one rank
         import torch
         import torch.distributed as dist
+        if world == 1:                 # ARMON_BENCH_FORCE_DIST without a launcher: a one-rank rendezvous on this host
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         # Rehearsal knob (one-GPU box): ARMON_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo with host
         # staging, to exercise this code path; real runs use one GPU per rank over RCCL.
         rehearsal = os.environ.get("ARMON_BENCH_REHEARSAL") == "1"

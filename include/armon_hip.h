@@ -92,7 +92,8 @@ ARMON_API int armon_hip_device_name(armon_ctx* ctx, char* buf, size_t buf_len);
 ARMON_API void* armon_hip_stream(armon_ctx* ctx);                              /* the hipStream_t in use     */
 /* Tuning knobs of the fused sweeps (measurement tools and tests; no reference counterpart). A context reads the
  * environment variables of the same names ONCE, when it is created; this call changes them afterwards.
- * "ARMON_XS_NITER" strips per wave of the X sweep, "ARMON_Y_SEG" rows per run of the Y march (0 = automatic),
+ * "ARMON_XS_NITER" strips per wave of the X sweep (values > 1 select the multi-strip form with its prefetch buffer, which only
+ * the A/B build libarmon_hip_alt.so carries; the product library runs one strip per wave), "ARMON_Y_SEG" rows per run of the Y march (0 = automatic),
  * "ARMON_SWEEP_ALIGN" 0 = unaligned block/strip origins, "ARMON_Y_COLS1" 1 = fp32 Y march with one column per lane.
  * None of them changes a result bit. */
 ARMON_API int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value);

@@ -373,11 +373,15 @@ def test_tune_placement_keeps_the_state(oracle):
 def test_tuning_knobs_do_not_change_results(monkeypatch, knobs, exact):
     """Block/strip origins, strips per wave and rows per run only decide WHO computes a cell: every setting
     gives the same bits (in both arithmetic flavours)."""
+    import contextlib
+    from armon_amd import _lib
     opts = dict(N=(333, 77), maxcycle=9, exact_arithmetic=exact)
     _p, ref_stats, ref = run("Sod_circ", **opts)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
-    _p, stats, host = run("Sod_circ", **opts)
+    # several strips per wave (with a prefetch buffer) is the round-2 form of the X sweep: the A/B build carries it
+    with (_lib.alt_kernels() if "ARMON_XS_NITER" in knobs else contextlib.nullcontext()):
+        _p, stats, host = run("Sod_circ", **opts)
     assert stats.cycles == ref_stats.cycles and stats.last_dt == ref_stats.last_dt
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(stats.data.real_view(host[k]), ref_stats.data.real_view(ref[k])), k
