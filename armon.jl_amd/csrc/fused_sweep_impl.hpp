@@ -525,20 +525,26 @@ constexpr int kXSRows = ARMON_XS_ROWS;
 // 3.444 -> 3.083, exact with tracking 3.818 -> 3.435, a 4096 x 8192 tile 0.415 -> 0.367. The multi-strip form stays in
 // the A/B build only (-DARMON_ALT_KERNELS, knob ARMON_XS_NITER > 1).
 constexpr int kXSNiter = 1;
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK, bool SINGLE>
+// ROW = 1 (with K = 1): the NARROW form for the LAG-wide boundary strips of a tile (partial sweeps of <= 8 cells along x,
+// which follow the halo exchange): a wave holds FOUR rows of 16 lanes instead of one row of 64 or 128 cells, neighbours by
+// row_shr / row_shl shifts. A 4-cell strip then costs 16 loaded cells per row instead of 128 (a strip of a 4096-cell-wide
+// tile: 3 % of the whole sweep -> 0.4 %). Same arithmetic per cell, hence the same bits.
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK, bool SINGLE, int ROW = 0>
 __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 {
-    using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, K, real>;
+    using SW = fused::SpatialSweep<SCHEME, LIM, PROJ, EOS, EXACT, K, real, ROW>;
     using St = fused::Strip<K, real>;
     constexpr int LAG = SW::LAG;
+    static_assert(ROW == 0 || K == 1, "the narrow form holds one cell per lane");
     // K = 2: 4 cells whatever the scheme (LAG <= 4), so that STRIDE = 120 cells = 15 whole 64-B sectors and every
     // strip's stores stay sector-aligned (Godunov + euler, LAG 2: -5.6 % time against HALO = 2, STRIDE = 124)
     constexpr int HALO = (K == 1) ? LAG : 4;
     static_assert(LAG <= 4, "strip halo");
-    constexpr int WIDTH = 64 * K;
+    constexpr int WIDTH = ROW ? 16 : 64 * K;
     constexpr int STRIDE = WIDTH - 2 * HALO;
+    constexpr int RW = ROW ? 4 : 1;                           // rows per wave
 
-    const int lane = threadIdx.x;
+    const int lane = ROW ? (threadIdx.x & 15) : threadIdx.x;  // position in the strip
     // XCD-aware placement of the workgroups: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own
     // L2), so with the plain mapping two strips that are neighbours along x — they share their 4-cell halos — always
     // sit on different XCDs and both fetch the shared sectors from HBM. Within every group of 8 rows of workgroups,
@@ -552,8 +558,8 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
             vbx = local >> 3;
         }
     }
-    const int64_t row_r = (int64_t)vby * kXSRows + threadIdx.y;
-    const bool row_ok = row_r < a.ny;                         // whole wave
+    const int64_t row_r = ((int64_t)vby * kXSRows + threadIdx.y) * RW + (ROW ? (threadIdx.x >> 4) : 0);
+    const bool row_ok = row_r < a.ny;                         // whole wave (ROW: a row of 16 lanes)
     const int64_t row = row_ok ? row_r : a.ny - 1;
     const int64_t row_off = (row + a.g) * a.row_len + a.g;
     const real* in[4] = {a.rho_in + row_off, a.ua_in + row_off, a.ut_in + row_off, a.E_in + row_off};
@@ -672,7 +678,7 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     // (18 MB at 16384², 0.1 % of the sweep's traffic); fold_dt_launch reduces them in two levels.
     if (TRACK) {
         const real au = red::wave_reduce<red::op_max>(cfl.au), av = red::wave_reduce<red::op_max>(cfl.av);
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             const int64_t wave_id = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kXSRows + threadIdx.y;
             st2(a.partials + 2 * wave_id, au, av);
         }
@@ -682,11 +688,11 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 #ifndef ARMON_XS_WAVES
 #define ARMON_XS_WAVES 1         // minimum waves per SIMD the X sweep is compiled for (tuning macro; 3 = cap at 168 VGPRs)
 #endif
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK, bool SINGLE = true>
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK, bool SINGLE = true, int ROW = 0>
 __global__ void __launch_bounds__(64 * kXSRows, ARMON_XS_WAVES)
 k_sweep_x_dpp(sweep_args a, int niter)
 {
-    sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK, SINGLE>(a, niter);
+    sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK, SINGLE, ROW>(a, niter);
 }
 
 // =====================================================================================================================
@@ -1097,6 +1103,15 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     niter = ctx->tune_xs_niter > 0 ? ctx->tune_xs_niter : 2;
 #endif
     const bool k1 = a.x_kernel == 3;
+    // the boundary strips of a tile (partial sweeps of at most 8 cells): four rows of 16 lanes per wave
+    if (a.x_kernel == 0 && a.o_hi - a.o_lo <= 8) {
+        const int64_t per_block = 16 - 2 * PIPE::LAG;
+        dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + 4 * kXSRows - 1) / (4 * kXSRows)));
+        *n_blocks = (int64_t)grid.x * grid.y * kXSRows;
+        hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK, true, 1>),
+                           grid, dim3(64, kXSRows), 0, ctx->stream, a, 1);
+        return check_launch("sweep_x_dpp (narrow)");
+    }
     const int halo = k1 ? PIPE::LAG : 4;
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
     dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));

@@ -33,7 +33,7 @@ __device__ __forceinline__ T block_reduce(T v, T* lds)
 // same bits (the two candidates are fl(|u| + |c|) and |fl(|u| - |c|)| in some order; rounding is monotone and symmetric).
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-k_dtCFL_partial(armon_range r, const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ c,
+k_dtCFL_partial(armon_range r, int rows_per_block, const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ c,
                 T* __restrict__ partials)
 {
     typedef T V2 __attribute__((ext_vector_type(2)));
@@ -44,8 +44,12 @@ k_dtCFL_partial(armon_range r, const T* __restrict__ u, const T* __restrict__ v,
         au = phys::amax(au, phys::abs_(uu) + phys::abs_(cc));
         av = phys::amax(av, phys::abs_(vv) + phys::abs_(cc));
     };
+    // workgroup (bx, by) reads rows_per_block CONSECUTIVE rows, and consecutive workgroups consecutive memory: the three
+    // streams are walked in address order (a grid that strides over the rows keeps 64 distant rows open at once)
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
+    const int64_t j_lo = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t j_hi = j_lo + rows_per_block < r.col_len ? j_lo + rows_per_block : r.col_len;
+    for (int64_t j = j_lo; j < j_hi; j++) {
         const int64_t base = r.col_start + j * r.col_step + r.row_start;
         constexpr uintptr_t mask = 2 * sizeof(T) - 1;
         const bool pairs = (((uintptr_t)(u + base) | (uintptr_t)(v + base) | (uintptr_t)(c + base)) & mask) == 0;   // uniform
@@ -130,9 +134,9 @@ k_conservation_partial(armon_range r, const T* __restrict__ rho, const T* __rest
 
 // Grid for a reduction over a range: enough workgroups to fill the chip (≈8 per CU), never more than
 // the range needs; each workgroup strides over rows (y) and row chunks (x).
-inline void reduce_grid(const armon_ctx* ctx, const armon_range& r, dim3& grid, int cells_per_thread = 1)
+inline void reduce_grid(const armon_ctx* ctx, const armon_range& r, dim3& grid)
 {
-    int64_t gx = (r.row_len + (int64_t)kBlock * cells_per_thread - 1) / ((int64_t)kBlock * cells_per_thread);
+    int64_t gx = (r.row_len + kBlock - 1) / kBlock;
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     int64_t target = (int64_t)ctx->n_cu * 8;
@@ -155,13 +159,21 @@ int dtCFL_async_impl(armon_ctx* ctx, armon_range r, T dx, T dy, const T* u, cons
     // the minimum over no cell is +inf (the reference's mapreduce has init = Inf, ref src/reductions.jl:79-87): an empty
     // range folds zero partials
     dim3 grid(1, 1, 1);
-    if (!range_empty(r)) reduce_grid(ctx, r, grid, 2);
+    int rows_per_block = 1;
+    if (!range_empty(r)) {
+        // two cells per thread across a row; as many consecutive rows per workgroup as keep the partials under 32768 pairs
+        const int64_t gx = (r.row_len + 2 * kBlock - 1) / (2 * kBlock);
+        int64_t rpb = (gx * r.col_len + 32767) / 32768;
+        if (rpb < 4) rpb = 4;
+        rows_per_block = (int)rpb;
+        grid = dim3((unsigned)gx, (unsigned)((r.col_len + rpb - 1) / rpb), 1);
+    }
     const int64_t n = range_empty(r) ? 0 : (int64_t)grid.x * grid.y;
     int rc = ensure_partials(ctx, (size_t)(n > 0 ? n : 1) * 2);
     if (rc != ARMON_OK) return rc;
     T* partials = reinterpret_cast<T*>(ctx->partials);
     if (n > 0) {
-        hipLaunchKernelGGL(k_dtCFL_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, u, v, c, partials);
+        hipLaunchKernelGGL(k_dtCFL_partial<T>, grid, dim3(kBlock), 0, ctx->stream, r, rows_per_block, u, v, c, partials);
         rc = check_launch("dtCFL_partial");
         if (rc != ARMON_OK) return rc;
     }

@@ -22,29 +22,39 @@ namespace fused {
 
 // value of the previous lane (cell i-1 for K = 1). Lane 0 has no source and reads 0 (bound_ctrl): it
 // is a halo lane whose results are discarded, and not keeping its own value saves a register copy per shift.
+// ROW = 0: the 64 lanes of the wave are one strip (wave_shr:1 / wave_shl:1); ROW = 1: four independent strips of 16
+// lanes each (row_shr:1 / row_shl:1; lanes 0 and 15 of every row read 0) — the form of the narrow boundary strips.
+template <int ROW = 0>
 __device__ __forceinline__ double from_prev_lane(double x)
 {
+    constexpr int ctrl = ROW ? 0x111 : 0x138;                          // row_shr:1 : wave_shr:1
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+template <int ROW = 0>
 __device__ __forceinline__ float from_prev_lane(float x)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));
+    constexpr int ctrl = ROW ? 0x111 : 0x138;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, true));
 }
 
-// value of the next lane; lane 63 reads 0
+// value of the next lane; lane 63 (lane 15 of a row) reads 0
+template <int ROW = 0>
 __device__ __forceinline__ double from_next_lane(double x)
 {
+    constexpr int ctrl = ROW ? 0x101 : 0x130;                          // row_shl:1 : wave_shl:1
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+template <int ROW = 0>
 __device__ __forceinline__ float from_next_lane(float x)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
+    constexpr int ctrl = ROW ? 0x101 : 0x130;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, true));
 }
 
 // Per-lane strip of K consecutive cells with access to the cells just outside it.
@@ -61,21 +71,21 @@ struct Shifted {      // v[k-1] for k = 0..K-1 ("left") or v[k+1] ("right")
     __device__ __forceinline__ T operator[](int k) const { return v[k]; }
 };
 
-template <int K, typename T>
+template <int ROW, int K, typename T>
 __device__ __forceinline__ Shifted<K, T> left_of(const Strip<K, T>& s)
 {
     Shifted<K, T> r;
-    r.v[0] = from_prev_lane(s.v[K - 1]);
+    r.v[0] = from_prev_lane<ROW>(s.v[K - 1]);
 #pragma unroll
     for (int k = 1; k < K; k++) r.v[k] = s.v[k - 1];
     return r;
 }
 
-template <int K, typename T>
+template <int ROW, int K, typename T>
 __device__ __forceinline__ Shifted<K, T> right_of(const Strip<K, T>& s)
 {
     Shifted<K, T> r;
-    r.v[K - 1] = from_next_lane(s.v[0]);
+    r.v[K - 1] = from_next_lane<ROW>(s.v[0]);
 #pragma unroll
     for (int k = 0; k < K - 1; k++) r.v[k] = s.v[k + 1];
     return r;
@@ -83,12 +93,15 @@ __device__ __forceinline__ Shifted<K, T> right_of(const Strip<K, T>& s)
 
 // One X sweep of the K cells held by each lane. In: pre-sweep (ρ, u, v, E). Out: post-sweep state, valid
 // for the cells at least LAG cells away from both ends of the wave's strip; p/c: EOS of the cells.
-template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, typename T = double>
+template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, typename T = double, int ROW = 0>
 struct SpatialSweep {
     using TR = PipeTraits<SCHEME, LIM, PROJ, EOS>;
     static constexpr int S = TR::S, W = TR::W, LAG = TR::LAG;
     using S_ = Strip<K, T>;
     using Sh = Shifted<K, T>;
+    // neighbour access of this sweep's strip shape (the whole wave, or rows of 16 lanes)
+    static __device__ __forceinline__ Sh left_of(const S_& s) { return fused::left_of<ROW, K, T>(s); }
+    static __device__ __forceinline__ Sh right_of(const S_& s) { return fused::right_of<ROW, K, T>(s); }
 
     T dt, dx, gamma;
 
