@@ -30,6 +30,7 @@ struct armon_ctx {
     int tune_align = 1;              // ARMON_SWEEP_ALIGN: 0 = unaligned block / strip origins
     int tune_y_cols1 = 0;            // ARMON_Y_COLS1: fp32 Y march with one column per lane
     int tune_x_xcd = 0;              // ARMON_X_XCD: XCD-aware workgroup placement in the X sweep
+    int tune_x_rows = 0;             // ARMON_X_ROWS: workgroup of the X sweep = 1: one strip of 4 rows, 2: 4 strips of one row, 0: by precision
     // y_run_length's last answer (it depends on the shape only)
     int64_t seg_nx = -1, seg_ny = -1;
     int seg_lag = -1, seg_value = 0;

@@ -77,6 +77,7 @@ struct sweep_args {
     int64_t x_first;               // X sweep: first cell of strip 0 (<= o_lo, sector-aligned in the ghosted row)
     int32_t xshift;                // Y sweep: columns the block origin is moved left (line-aligned row segments)
     int32_t xcd_remap;             // X sweep: XCD-aware workgroup placement (ARMON_X_XCD)
+    int32_t x_wg_along_x = 0;      // X sweep: a workgroup = kXSRows consecutive strips of one row (else: one strip of kXSRows rows)
     real dt, dx, gamma;
     real fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const real *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
@@ -558,7 +559,14 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
             vbx = local >> 3;
         }
     }
-    const int64_t row_r = ((int64_t)vby * kXSRows + threadIdx.y) * RW + (ROW ? (threadIdx.x >> 4) : 0);
+    // Which strip and row a wave takes. a.x_wg_along_x: the kXSRows waves of a workgroup take kXSRows CONSECUTIVE STRIPS of
+    // ONE row (the 128-B lines two neighbouring strips share — a strip's loads start 32 B before its sector-aligned stores —
+    // are then fetched once per workgroup, from its CU's L1, instead of by two workgroups on two XCDs); otherwise one strip
+    // of kXSRows consecutive rows (the narrow form, blocks of more than 65535 rows, the A/B forms).
+    const bool along_x = SINGLE && ROW == 0 && a.x_wg_along_x;
+    const int64_t strip0 = along_x ? (int64_t)vbx * kXSRows + threadIdx.y : (int64_t)vbx * niter;
+    const int64_t row_r = along_x ? (int64_t)vby
+                                  : ((int64_t)vby * kXSRows + threadIdx.y) * RW + (ROW ? (threadIdx.x >> 4) : 0);
     const bool row_ok = row_r < a.ny;                         // whole wave (ROW: a row of 16 lanes)
     const int64_t row = row_ok ? row_r : a.ny - 1;
     const int64_t row_off = (row + a.g) * a.row_len + a.g;
@@ -572,7 +580,7 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     cfl_track cfl;
     // Strip origins are aligned so that a strip's stores start on a 64-B sector of the ghosted row (for the
     // usual STRIDE = 120 = 15 sectors); the first strip of a row is then a short one (stores masked below o_lo).
-    const int64_t w_first = a.x_first + (int64_t)vbx * niter * STRIDE;
+    const int64_t w_first = a.x_first + strip0 * STRIDE;
     // Strips are real-buffered in registers: the loads of strip it+1 are issued before strip it is
     // computed (the loop is unrolled by the two buffers, so no loaded register is ever copied).
     St buf[2][4];
@@ -1115,6 +1123,8 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     const int halo = k1 ? PIPE::LAG : 4;
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
     dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
+    if (a.x_wg_along_x && !k1 && niter == 1)                  // kXSRows strips of one row per workgroup
+        grid = dim3((unsigned)((a.o_hi - a.x_first + kXSRows * per_block - 1) / (kXSRows * per_block)), (unsigned)a.ny);
     *n_blocks = (int64_t)grid.x * grid.y * kXSRows;          // one pair of maxima per wave
 #if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
     if (k1)
@@ -1179,7 +1189,8 @@ int64_t max_blocks(const sweep_args& a)
 #else
     const int64_t bx_lds = 0;
 #endif
-    const int64_t bx_dpp = ((a.nx + 8) / 56 + 1) * ((a.ny + kXSRows - 1) / kXSRows) * kXSRows;     // per wave; niter >= 1, K = 1, LAG = 4
+    // per wave; niter >= 1, K = 1, LAG = 4; + kXSRows: a row's strips are rounded up to whole workgroups (x_wg_along_x)
+    const int64_t bx_dpp = ((a.nx + 8) / 56 + 1 + kXSRows) * ((a.ny + kXSRows - 1) / kXSRows) * kXSRows;
     int64_t m = by > bx_lds ? by : bx_lds;
     m = m > bx_dpp ? m : bx_dpp;
     return m + kFoldBlocks;                                   // + the first-level results of fold_dt_launch
@@ -1303,6 +1314,11 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.xshift = (X || !align) ? 0 : d->nghost % 16;
     a.x_first = X ? (align ? a.o_lo - (a.o_lo + d->nghost) % 8 : a.o_lo) : 0;
     a.xcd_remap = ctx->tune_x_xcd;
+    // workgroup shape of the X sweep (profiles/r03_ab_x_workgroup_shape.txt): 4 consecutive strips of one row pay for fp32
+    // (1.54 -> 1.43 ms at 16384²: a 512-B strip shares a quarter of its 128-B lines with its neighbours) and not for fp64
+    // (equal at 16384² and 4096 x 8192, +3 % at 8192²), which keeps one strip of 4 rows. ARMON_X_ROWS: 1 / 2 force a shape.
+    const bool want_along_x = ctx->tune_x_rows == 2 || (ctx->tune_x_rows == 0 && sizeof(real) == 4);
+    a.x_wg_along_x = (X && want_along_x && d->ny <= 65535 && !ctx->tune_x_xcd) ? 1 : 0;              // grid.y carries the rows
     a.partials = nullptr;
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));

@@ -124,3 +124,19 @@ def test_f32_two_column_y_march_equals_the_one_column_form(monkeypatch, test, N)
     assert s1.cycles == s2.cycles and s1.last_dt == s2.last_dt
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(h1[k], h2[k]), k
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+@pytest.mark.parametrize("test,N,opts", [("Sod_circ", (517, 77), {}), ("Sod_circ", (130, 40), dict(axis_splitting="Godunov")),
+                                         ("Bizarrium", (1000, 9), dict(axis_splitting="X_only"))])
+def test_f32_x_sweep_workgroup_shapes_give_the_same_bits(monkeypatch, test, N, opts, exact):
+    """fp32 X sweeps put 4 consecutive strips of ONE row in a workgroup (fp64: one strip of 4 rows): who computes a cell
+    must not change it — also on the cycles that end with a dt-tracking X sweep."""
+    o = dict(N=N, maxcycle=9, use_fused_sweep=True, exact_arithmetic=exact, **opts)
+    _p, s0, h0 = run32(test, **o)
+    for shape in ("1", "2"):
+        monkeypatch.setenv("ARMON_X_ROWS", shape)
+        _p, s1, h1 = run32(test, **o)
+        assert s1.cycles == s0.cycles and s1.last_dt == s0.last_dt
+        for k in ("rho", "u", "v", "E", "p"):
+            assert np.array_equal(h1[k], h0[k]), (shape, k)

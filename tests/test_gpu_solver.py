@@ -367,7 +367,7 @@ def test_tune_placement_keeps_the_state(oracle):
 
 @pytest.mark.parametrize("knobs", [dict(ARMON_SWEEP_ALIGN="0"), dict(ARMON_XS_NITER="1"), dict(ARMON_XS_NITER="3"),
                                    dict(ARMON_XS_NITER="137"), dict(ARMON_Y_SEG="16"), dict(ARMON_Y_SEG="1000"), dict(ARMON_X_XCD="1"),
-                                   dict(ARMON_X_XCD="0")],
+                                   dict(ARMON_X_XCD="0"), dict(ARMON_X_ROWS="1"), dict(ARMON_X_ROWS="2")],
                          ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 @pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
 def test_tuning_knobs_do_not_change_results(monkeypatch, knobs, exact):
