@@ -138,5 +138,5 @@ def test_f32_x_sweep_workgroup_shapes_give_the_same_bits(monkeypatch, test, N, o
         monkeypatch.setenv("ARMON_X_ROWS", shape)
         _p, s1, h1 = run32(test, **o)
         assert s1.cycles == s0.cycles and s1.last_dt == s0.last_dt
-        for k in ("rho", "u", "v", "E", "p"):
-            assert np.array_equal(h1[k], h0[k]), (shape, k)
+        for k in ("rho", "u", "v", "E", "p"):       # real cells: the ghost rows of a ping-pong partner are never written
+            assert np.array_equal(s1.data.real_view(h1[k]), s0.data.real_view(h0[k])), (shape, k)
