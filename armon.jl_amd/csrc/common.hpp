@@ -33,7 +33,7 @@ struct armon_ctx {
     int tune_x_rows = 0;             // ARMON_X_ROWS: workgroup of the X sweep = 1: one strip of 4 rows, 2: 4 strips of one row, 0: by precision
     // y_run_length's last answer (it depends on the shape only)
     int64_t seg_nx = -1, seg_ny = -1;
-    int seg_lag = -1, seg_value = 0;
+    int seg_lag = -1, seg_cols = -1, seg_value = 0;
 };
 
 namespace armon {

@@ -467,8 +467,15 @@ k_sweep_y2(sweep_args a)
         constexpr bool CHECKED = decltype(checked)::value;
         load(integral_constant<int, PH8 + PF>{}, checked);   // row j + PF → slot (j + PF) mod 8
         real p0, c0, cl0, p1, c1, cl1;
+#ifdef ARMON_PROBE_NOCOMPUTE   // calibration build: same loads/stores, no arithmetic (tools/build_variant.sh)
+        p0 = c0 = cl0 = p1 = c1 = cl1 = 0;
+        const auto& cc0 = pipe[0].c[PH8 & 7];
+        const auto& cc1 = pipe[1].c[PH8 & 7];
+        const fused::Out4<real> out0{cc0.rho, cc0.ua, cc0.ut, cc0.E}, out1{cc1.rho, cc1.ua, cc1.ut, cc1.E};
+#else
         const fused::Out4<real> out0 = pipe[0].template advance<true, PH8>(p0, c0, cl0);
         const fused::Out4<real> out1 = pipe[1].template advance<true, PH8>(p1, c1, cl1);
+#endif
         const int o = j - LAG;
         if (CHECKED) {
             if (a.emit && j >= o0 && j < o1 && active) {
@@ -1153,10 +1160,10 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
 // of long-lived workgroups exposes the whole ramp-up and tail: 4096², 137 rows in one round is 5 % slower than 32
 // rows in 4.25). Measured at 16384² (tools/y_ab_r02.sh, one process): 128 rows 3.17 ms, 256: 3.12, 421: 3.09,
 // 529: 3.08, 713: 3.09, 1093: 3.12, 2341 (one round, 11 % of the slots empty): 3.19.
-int y_run_length(int n_cu, int64_t nx, int64_t ny, int lag)
+int y_run_length(int n_cu, int64_t nx, int64_t ny, int lag, int cols_per_lane)
 {
     const double slots = (double)n_cu * ARMON_Y_WAVES * 4 / (kYBlock / 64);         // workgroups resident at once
-    const int64_t cols = (nx + 16 + kYBlock - 1) / kYBlock;
+    const int64_t cols = (nx + 16 + (int64_t)kYBlock * cols_per_lane - 1) / ((int64_t)kYBlock * cols_per_lane);
     int best = (int)(ny < 32 ? ny : 32);
     double best_cost = 1e300;
     for (int64_t nruns = 1; nruns <= ny; nruns++) {
@@ -1290,8 +1297,12 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     } else if (ctx->tune_y_seg > 0) {
         a.seg = ctx->tune_y_seg;
     } else {
-        if (ctx->seg_nx != d->nx || ctx->seg_ny != n_axis || ctx->seg_lag != lag) {
-            ctx->seg_value = y_run_length(ctx->n_cu, d->nx, n_axis, lag);
+        // the tuned fp32 march holds two columns per lane (k_sweep_y2, same condition as in launch()): half the workgroups per row
+        const int cols_per_lane = (std::is_same<real, float>::value && !d->exact && d->nx % 2 == 0 && d->nghost % 2 == 0 &&
+                                   d->nx >= 2 && !ctx->tune_y_cols1) ? 2 : 1;
+        if (ctx->seg_nx != d->nx || ctx->seg_ny != n_axis || ctx->seg_lag != lag || ctx->seg_cols != cols_per_lane) {
+            ctx->seg_value = y_run_length(ctx->n_cu, d->nx, n_axis, lag, cols_per_lane);
+            ctx->seg_cols = cols_per_lane;
             ctx->seg_nx = d->nx;
             ctx->seg_ny = n_axis;
             ctx->seg_lag = lag;

@@ -8,18 +8,19 @@ if ROOT not in sys.path:
 
 
 def _init(rank, world, port, backend="gloo"):
+    """`port` = the rendezvous token of test_distributed.free_port(): the path of a file store (no TCP port to collide on)."""
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"] = str(rank)
     os.environ["WORLD_SIZE"] = str(world)
     os.environ["LOCAL_RANK"] = "0"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")      # RCCL's own bootstrap still wants an address
+    method = "file://" + str(port)
     if backend == "nccl":
         import torch
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", init_method=method, rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", init_method=method, rank=rank, world_size=world)
     return dist
 
 
@@ -167,6 +168,14 @@ def rccl_periodic_worker(rank, world, port, mode, N, test, opts, out_dir):
         sums = comm.allreduce_host([1.0, 2.0], "sum")
         if sums != [1.0, 2.0]:
             errors.append(("allreduce_host", sums))
+        # a NaN time step must survive the RCCL minimum (ncclMin may drop a NaN operand): it travels as -inf, which fails
+        # the host's validity check just as well (ref src/solver_state.jl:123-124)
+        scalar.copy_from_host(np.array([np.nan, 0.], dtype=dtype))
+        comm.allreduce_min_device_async(scalar)
+        params.wait()
+        got = float(scalar.to_host()[0])
+        if not (got == -np.inf or np.isnan(got)):
+            errors.append(("nan through the dt all-reduce", got))
     with open(os.path.join(out_dir, "rank0.txt"), "w") as f:
         f.write("OK\n" if not errors else f"FAIL {errors[:8]}\n")
         f.write(f"{sorted((int(s), n) for s, n in params.neighbours.items())}\n")

@@ -7,11 +7,15 @@ import dist_workers
 
 
 def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous token for one spawn: the workers meet through a FILE store (tests/dist_workers._init), not a TCP port —
+    a port found free here can be taken (or still be in TIME_WAIT) by the time the workers bind it, which made one run in
+    six of the GPU suite fail with EADDRINUSE."""
+    import os
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="armon_rdv_", dir="/tmp")
+    os.close(fd)
+    os.unlink(path)                      # the store creates it
+    return path
 
 
 def spawn(fn, world, *args):
