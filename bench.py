@@ -63,7 +63,7 @@ class EventTimer:
         return out
 
 
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic_fused_fast_sod16384.json"
+PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic_fused_fast_sod16384.json"
 
 
 def pmc_traffic(args, world, N_global):
@@ -74,7 +74,7 @@ def pmc_traffic(args, world, N_global):
     if (world != 1 or args.staged or args.exact or args.f32 or tuple(N_global) != (16384, 16384) or args.test != "Sod"
             or args.scheme != "GAD"):
         return None, None
-    for rel in (PMC_TRAFFIC_FILE, "profiles/r01_pmc_traffic_fused_fast_sod16384.json"):
+    for rel in (PMC_TRAFFIC_FILE, "profiles/r02_pmc_traffic_fused_fast_sod16384.json"):
         try:
             ks = json.load(open(os.path.join(ROOT, rel)))["kernels"]
             return round(sum(k["traffic_bytes_per_launch"] for k in ks.values()) / len(ks)), rel + " (replayed, not measured in this run)"
