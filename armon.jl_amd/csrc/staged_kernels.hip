@@ -118,7 +118,10 @@ k_acoustic_GAD(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us,
 //    window of the last two cells and three solutions. kGadRows fluxes per kGadRows + 2 solves.
 // No cell outside the reference's own stencil [i - 2s, i + s] of the range is read.
 constexpr int kGadValid = 62;
-constexpr int kGadRows = 64;
+#ifndef ARMON_GAD_ROWS
+#define ARMON_GAD_ROWS 64        // rows per thread of the y form (tuning macro)
+#endif
+constexpr int kGadRows = ARMON_GAD_ROWS;
 
 template <int LIM, typename T>
 __global__ void __launch_bounds__(kBlock)
