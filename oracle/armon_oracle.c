@@ -472,6 +472,23 @@ static void update_eos(const armon_oracle_run* run, const armon_oracle_block_dat
         armon_oracle_perfect_gas_EOS(r, 7. / 5., d->rho, d->E, d->u, d->v, d->p, d->c, d->g);
 }
 
+/* TEST AID (no reference counterpart): periodic ghosts along `axis` — layer l outside the low side holds the cell l in from
+ * the high side, and vice versa, for the 7 variables the boundary conditions write (ref src/halo_exchange.jl:2-29). */
+static void periodic_ghosts(const armon_oracle_run* run, const armon_oracle_block_data* d, int axis)
+{
+    const int64_t nx = run->nx, ny = run->ny, g = run->nghost, row = nx + 2 * g;
+    real* vars[7] = {d->rho, d->u, d->v, d->p, d->c, d->g, d->E};
+    const int64_t n = (axis == ARMON_AXIS_X) ? nx : ny, m = (axis == ARMON_AXIS_X) ? ny : nx;
+    const int64_t s = (axis == ARMON_AXIS_X) ? 1 : row, t = (axis == ARMON_AXIS_X) ? row : 1;
+    const int64_t first = g * row + g;                       /* first real cell */
+    for (int64_t k = 0; k < m; k++)
+        for (int64_t l = 0; l < g; l++)
+            for (int v = 0; v < 7; v++) {
+                vars[v][first + k * t + (-1 - l) * s] = vars[v][first + k * t + (n - 1 - l) * s];
+                vars[v][first + k * t + (n + l) * s] = vars[v][first + k * t + l * s];
+            }
+}
+
 /* one directional sweep: ref src/solver.jl:300-316; ranges ref src/parameters.jl:988-1025 */
 static void sweep(const armon_oracle_run* run, const armon_oracle_block_data* d, int axis, real dt)
 {
@@ -488,7 +505,8 @@ static void sweep(const armon_oracle_run* run, const armon_oracle_block_data* d,
     update_eos(run, d);
 
     /* BC on both sides of the sweep axis: ref src/halo_exchange.jl:32-36,323-354 */
-    for (int hs = 0; hs < 2; hs++) {
+    if (run->periodic[axis]) periodic_ghosts(run, d, axis);
+    else for (int hs = 0; hs < 2; hs++) {
         int side = (axis == ARMON_AXIS_X) ? (hs ? ARMON_SIDE_RIGHT : ARMON_SIDE_LEFT)
                                           : (hs ? ARMON_SIDE_TOP : ARMON_SIDE_BOTTOM);
         real uf = 1., vf = 1.;

@@ -92,6 +92,10 @@ typedef struct {
     double solve_seconds;
     real  initial_mass, initial_energy, final_mass, final_energy;
     int32_t status;   /* 0 ok, ARMON_ERR_INVALID_DT */
+    /* TEST AID, not in the reference (its domain is never periodic): the ghosts of that axis are filled from the OPPOSITE
+     * border instead of the mirror — the independent check of the library's periodic transport runs (the test aid
+     * armon_hip_mgpu_set_periodic, tests/test_gpu_transport.py). 0, 0 = the reference's boundary conditions. */
+    int32_t periodic[2];
 } armon_oracle_run;
 
 /* Allocates nothing: `data` holds 16 caller-provided arrays of (nx+2g)(ny+2g) doubles.

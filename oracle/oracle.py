@@ -52,7 +52,7 @@ def _run_struct(real):
                     ("solve_seconds", C.c_double),
                     ("initial_mass", real), ("initial_energy", real),
                     ("final_mass", real), ("final_energy", real),
-                    ("status", C.c_int32)]
+                    ("status", C.c_int32), ("periodic", C.c_int32 * 2)]
     return _Run
 
 
@@ -143,8 +143,9 @@ def block_data(fields):
 def solve(test="Sod", N=(100, 100), scheme="GAD", riemann_limiter="minmod", projection="euler_2nd",
           axis_splitting="Sequential", nghost=4, cfl=0., maxtime=0., maxcycle=500_000,
           cst_dt=False, Dt=0., domain_size=None, origin=None, threads=1, native=False,
-          fields=None, skip_init=False, data_type=np.float64):
-    """Run the oracle's armon(): returns (Run, fields dict). Option names follow ArmonParameters."""
+          fields=None, skip_init=False, data_type=np.float64, periodic=(False, False)):
+    """Run the oracle's armon(): returns (Run, fields dict). Option names follow ArmonParameters. ``periodic``: test aid (not
+    in the reference): ghosts of that axis from the opposite border instead of the mirror."""
     f32 = np.dtype(data_type) == np.float32
     L = lib(native, f32=f32)
     L.armon_oracle_set_threads(threads)
@@ -162,6 +163,7 @@ def solve(test="Sod", N=(100, 100), scheme="GAD", riemann_limiter="minmod", proj
     run.maxtime = maxtime if maxtime != 0 else d["maxtime"]
     run.maxcycle = maxcycle
     run.cst_dt, run.Dt = int(cst_dt), Dt
+    run.periodic[0], run.periodic[1] = int(bool(periodic[0])), int(bool(periodic[1]))
     if fields is None:
         fields = alloc_fields(nx, ny, nghost, dtype=np.float32 if f32 else np.float64)
     bd = block_data(fields)

@@ -63,14 +63,19 @@ def test_run_over_rccl_self_exchange_equals_plain_run(tmp_path, test, periodic, 
     ("Bizarrium", (64, 48), dict(maxcycle=10)),
     ("Sedov", (60, 60), dict(maxcycle=10, axis_splitting="Godunov")),
 ])
-def test_doubly_periodic_run_is_the_same_through_every_transport(tmp_path, test, N, opts):
-    """A doubly periodic problem has no plain counterpart, so the transports are held against each other: the 1 x 1 rank
-    over RCCL (send/recv to itself), the in-process 1 x 1 and 2 x 2 groups with plain device copies, and the 2 x 1 / 2 x 2
-    groups with forced hipMemcpyPeerAsync (faces AND the several-device dt reduction) — same bits, dt and cycle count."""
+def test_doubly_periodic_run_is_the_same_through_every_transport(tmp_path, oracle, test, N, opts):
+    """A doubly periodic problem has no plain counterpart in the library, so (1) the transports are held against each other:
+    the 1 x 1 rank over RCCL (send/recv to itself), the in-process 1 x 1 and 2 x 2 groups with plain device copies, and the
+    2 x 1 / 2 x 2 groups with forced hipMemcpyPeerAsync (faces AND the several-device dt reduction) — same bits, dt and cycle
+    count; and (2) all of them against the CPU oracle with periodic ghosts (a test aid of the oracle too): bit for bit."""
     from armon_amd.multi_tile import TileGroup
     o = dict(opts, use_fused_sweep=True, exact_arithmetic=True)
     spawn(dist_workers.rccl_periodic_worker, 1, "run", N, test, dict(o, periodic=(True, True)), str(tmp_path))
     t = np.load(tmp_path / "tile0.npz")
+    orun, f = oracle.solve(test=test, N=N, periodic=(True, True), **opts)
+    assert int(t["cycles"]) == orun.cycles and float(t["dt"]) == orun.last_dt and float(t["time"]) == orun.final_time
+    for k in ("rho", "u", "v", "E", "p"):
+        assert np.array_equal(t[k], oracle.real_view(f[k], N[0], N[1], 4)), k
     for P, force in (((1, 1), False), ((2, 2), False), ((2, 1), True), ((2, 2), True)):
         group = TileGroup(P, test=test, N=N, silent=5, periodic=(True, True), force_peer_copy=force, **o)
         try:
