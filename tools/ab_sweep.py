@@ -27,6 +27,7 @@ ap.add_argument("--scheme", default="GAD")
 ap.add_argument("--projection", default="euler_2nd")
 ap.add_argument("--f32", action="store_true")
 ap.add_argument("--track-x", action="store_true", help="fused dt/CFL reduction on the X sweep too (X-last splittings)")
+ap.add_argument("--no-track-y", action="store_true", help="Y sweep without the fused dt/CFL reduction (a cycle's first sweep in Y-first splittings)")
 ap.add_argument("--env", default="", help="per-build tuning knobs: name:KEY=VAL,KEY=VAL;name2:... (armon_hip_set_tuning on that build's context)")
 ap.add_argument("--gap-ms", type=float, default=0., help="idle time before every launch (clock/power recovery experiments)")
 ap.add_argument("--copy", action="store_true", help="also time armon_hip_stream_copy4 on the same arrays (same bytes, no arithmetic)")
@@ -61,7 +62,7 @@ res = {}
 knobs = sorted({k for e in envs.values() for k in e})
 for r in range(args.rounds + 2):
     for axis in (Axis.X, Axis.Y):
-        d = sweep_desc(params, grid, axis, dt, dx, emit_dt=axis == Axis.Y or args.track_x)
+        d = sweep_desc(params, grid, axis, dt, dx, emit_dt=(axis == Axis.Y and not args.no_track_y) or (axis == Axis.X and args.track_x))
         for name, L, ctx in builds:
             for k in knobs:                       # knobs live in the context: reset, then apply this build's values
                 _lib.check(L.armon_hip_set_tuning(ctx, k.encode(), int(envs.get(name, {}).get(k, -1 if k == "ARMON_SWEEP_ALIGN" else 0))))
