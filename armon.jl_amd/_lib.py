@@ -55,7 +55,17 @@ class SweepDesc(C.Structure):
                 ("rho_out", C.c_void_p), ("u_out", C.c_void_p), ("v_out", C.c_void_p), ("E_out", C.c_void_p),
                 ("p_out", C.c_void_p), ("c_out", C.c_void_p),
                 ("dt_cfl_out", C.c_void_p), ("cfl_dx", C.c_double), ("cfl_dy", C.c_double),
-                ("out_lo", C.c_int64), ("out_hi", C.c_int64), ("dt_accumulate", C.c_int32), ("reserved", C.c_int32)]
+                ("out_lo", C.c_int64), ("out_hi", C.c_int64), ("dt_accumulate", C.c_int32), ("reserved", C.c_int32),
+                ("dt_state", C.c_void_p)]
+
+
+class DtState(C.Structure):
+    """armon_dt_state — GlobalTimeStep on the device (include/armon_hip.h)."""
+    _fields_ = [("current_dt", C.c_double), ("time", C.c_double), ("L_prev", C.c_double), ("cycle", C.c_int64),
+                ("done", C.c_int32), ("invalid", C.c_int32), ("emit_p", C.c_int32), ("pad", C.c_int32),
+                ("invalid_cycle", C.c_int64), ("invalid_value", C.c_double),
+                ("auto_step", C.c_int32), ("cst_dt", C.c_int32), ("maxcycle", C.c_int64),
+                ("cfl", C.c_double), ("maxtime", C.c_double), ("Dt", C.c_double)]
 
 
 class HaloDesc(C.Structure):
@@ -114,6 +124,12 @@ SIGNATURES = {
                                   C.POINTER(_i64 * 2), C.POINTER(_dbl * 2), C.POINTER(_dbl * 2),
                                   _dbl, C.POINTER(BlockDataPtrs)]),
     "armon_hip_sweep": (_ci, [_vp, C.POINTER(SweepDesc)]),
+    "armon_hip_dt_state_step": (_ci, [_vp, _vp, _vp, _dbl, _dbl, _i64, _ci, _dbl]),
+    "armon_hip_dt_state_step_f32": (_ci, [_vp, _vp, _vp, _dbl, _dbl, _i64, _ci, _dbl]),
+    "armon_hip_graph_begin": (_ci, [_vp]),
+    "armon_hip_graph_end": (_ci, [_vp, C.POINTER(_vp)]),
+    "armon_hip_graph_launch": (_ci, [_vp, _vp]),
+    "armon_hip_graph_destroy": (_ci, [_vp]),
     "armon_hip_tune_placement": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc), C.POINTER(_vp), _ci,
                                        C.c_size_t, _ci, C.POINTER(_ci * 8), C.POINTER(_dbl)]),
     "armon_hip_cycle_xy": (_ci, [_vp, C.POINTER(SweepDesc), C.POINTER(SweepDesc)]),

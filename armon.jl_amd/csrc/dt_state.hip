@@ -1,0 +1,102 @@
+// dt_state.hip — the reference's GlobalTimeStep (ref src/solver_state.jl:30-166) as device-resident state, and the replay
+// of a captured cycle (hipGraph).
+//
+// The reference's time loop (ref src/solver.jl:323-403) reads two scalars on the host every cycle: the reduced CFL step
+// (update_dt!, :102-142) and, through it, the time that decides whether to go on (:350). On the device path a cycle is two
+// to three kernel launches, so for small grids those host round trips and the launch calls themselves are the cycle time.
+// Here update_dt! + next_cycle! + the exit test run as ONE one-thread kernel after the last sweep of a cycle, the sweeps
+// read their time step from the state (armon_sweep_desc::dt_state), and a whole cycle can be captured once and replayed
+// with a single call per cycle; the host looks at the state every few cycles, asynchronously.
+#include "common.hpp"
+#include "dt_state.hpp"
+
+#include <cmath>
+
+using namespace armon;
+
+struct armon_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+
+template <typename T>
+__global__ void k_dt_state_step(armon_dt_state* __restrict__ st, const T* __restrict__ L_new, T cfl, T maxtime,
+                                int64_t maxcycle, int cst_dt, T Dt)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    dt_state_step<T>(st, cst_dt ? T(0) : L_new[0], cfl, maxtime, maxcycle, cst_dt, Dt);
+}
+
+template <typename T>
+int step_impl(armon_ctx* ctx, armon_dt_state* st, const T* L_new, double cfl, double maxtime, int64_t maxcycle, int cst_dt,
+              double Dt)
+{
+    ARMON_REQUIRE(ctx && st, "NULL argument");
+    ARMON_REQUIRE(cst_dt || L_new, "the reduced CFL step (dt_cfl_out of the cycle's last sweep) is needed unless cst_dt");
+    hipLaunchKernelGGL(k_dt_state_step<T>, dim3(1), dim3(1), 0, ctx->stream, st, L_new, (T)cfl, (T)maxtime, maxcycle, cst_dt, (T)Dt);
+    return check_launch("dt_state_step");
+}
+
+}  // namespace
+
+extern "C" {
+
+int armon_hip_dt_state_step(armon_ctx* ctx, armon_dt_state* st, const double* L_new, double cfl, double maxtime,
+                            int64_t maxcycle, int cst_dt, double Dt)
+{
+    return step_impl<double>(ctx, st, L_new, cfl, maxtime, maxcycle, cst_dt, Dt);
+}
+
+int armon_hip_dt_state_step_f32(armon_ctx* ctx, armon_dt_state* st, const float* L_new, double cfl, double maxtime,
+                                int64_t maxcycle, int cst_dt, double Dt)
+{
+    return step_impl<float>(ctx, st, L_new, cfl, maxtime, maxcycle, cst_dt, Dt);
+}
+
+int armon_hip_graph_begin(armon_ctx* ctx)
+{
+    ARMON_REQUIRE(ctx, "ctx is NULL");
+    ARMON_HIP_TRY(hipSetDevice(ctx->device));
+    ARMON_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return ARMON_OK;
+}
+
+int armon_hip_graph_end(armon_ctx* ctx, armon_graph** out)
+{
+    ARMON_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    hipGraph_t graph = nullptr;
+    ARMON_HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+    ARMON_REQUIRE(graph, "nothing was captured");
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return fail_hip(e, "hipGraphInstantiate");
+    }
+    armon_graph* g = new armon_graph();
+    g->graph = graph;
+    g->exec = exec;
+    *out = g;
+    return ARMON_OK;
+}
+
+int armon_hip_graph_launch(armon_ctx* ctx, armon_graph* g)
+{
+    ARMON_REQUIRE(ctx && g && g->exec, "NULL argument");
+    ARMON_HIP_TRY(hipGraphLaunch(g->exec, ctx->stream));
+    return ARMON_OK;
+}
+
+int armon_hip_graph_destroy(armon_graph* g)
+{
+    if (!g) return ARMON_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return ARMON_OK;
+}
+
+}  // extern "C"

@@ -21,6 +21,7 @@
 // ARMON_Y_PF, ARMON_Y_WAVES, ARMON_Y_BLOCK, ARMON_PROBE_NOCOMPUTE, ARMON_ONLY_HEADLINE.
 #pragma once
 #include "common.hpp"
+#include "dt_state.hpp"
 #include "reduce.hpp"
 #include "sweep_pipeline.hpp"
 #include "sweep_spatial.hpp"
@@ -78,6 +79,7 @@ struct sweep_args {
     int32_t xshift;                // Y sweep: columns the block origin is moved left (line-aligned row segments)
     int32_t xcd_remap;             // X sweep: XCD-aware workgroup placement (ARMON_X_XCD)
     int32_t x_wg_along_x = 0;      // X sweep: a workgroup = kXSRows consecutive strips of one row (else: one strip of kXSRows rows)
+    armon_dt_state* st = nullptr;   // device-resident time step (graph replay): dt is then a factor of st->current_dt
     real dt, dx, gamma;
     real fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const real *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
@@ -107,6 +109,19 @@ __device__ __forceinline__ int64_t bc_source(const sweep_args& a, int64_t n, int
         return 2 * n - 1 - j;
     }
     return j;
+}
+
+// Device-resident time step (armon_dt_state): nothing to do once the time loop is over; otherwise the sweep's step is its
+// factor times the cycle's step — the product the host forms in the run's precision (ref src/solver_state.jl:339-345) —
+// and p is only materialised on the cycle the state machine marked as the last one.
+__device__ __forceinline__ bool sweep_begin(sweep_args& a)
+{
+    if (a.st) {
+        if (a.st->done) return false;
+        a.dt = (real)a.st->current_dt * a.dt;
+        if (!a.st->emit_p) a.emit &= ~1;
+    }
+    return true;
 }
 
 template <int... Is, class F>
@@ -220,8 +235,9 @@ k_fold_pairs(const real* __restrict__ partials, int64_t n, real* __restrict__ ou
 
 __global__ void __launch_bounds__(256)
 k_fold_dt(const real* __restrict__ partials, int64_t n_blocks, real dx, real dy, real* __restrict__ out,
-          int accumulate)
+          int accumulate, armon_dt_state* st = nullptr)
 {
+    if (st && st->done) return;                     // the sweep did nothing either (graph replay past the last cycle)
     __shared__ real lds[4];
     real au = 0, av = 0;
     for (int64_t k = threadIdx.x; k < n_blocks; k += blockDim.x) {
@@ -233,11 +249,15 @@ k_fold_dt(const real* __restrict__ partials, int64_t n_blocks, real dx, real dy,
     if (threadIdx.x == 0) {
         const real dt = phys::mn_nan(dx / au, dy / av);             // a NaN maximum gives a NaN step, and it wins
         out[0] = accumulate ? phys::mn_nan(out[0], dt) : dt;
+        // graph replay: the state machine steps right here instead of in a kernel of its own (armon_dt_state::auto_step)
+        if (st && st->auto_step && !accumulate)
+            dt_state_step<real>(st, dt, (real)st->cfl, (real)st->maxtime, st->maxcycle, st->cst_dt, (real)st->Dt);
     }
 }
 
 // min(dx / max au, dy / max av) over `n` partial pairs into *out, on the context's stream
-int fold_dt_launch(armon_ctx* ctx, real* partials, int64_t n, real dx, real dy, real* out, int accumulate)
+int fold_dt_launch(armon_ctx* ctx, real* partials, int64_t n, real dx, real dy, real* out, int accumulate,
+                   armon_dt_state* st = nullptr)
 {
     if (n > 16384) {
         real* level1 = partials + 2 * n;                      // room reserved by max_blocks()
@@ -247,7 +267,7 @@ int fold_dt_launch(armon_ctx* ctx, real* partials, int64_t n, real dx, real dy, 
         partials = level1;
         n = kFoldBlocks;
     }
-    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, partials, n, dx, dy, out, accumulate);
+    hipLaunchKernelGGL(k_fold_dt, dim3(1), dim3(256), 0, ctx->stream, partials, n, dx, dy, out, accumulate, st);
     return check_launch("fold_dt");
 }
 
@@ -267,6 +287,7 @@ template <class PIPE, bool TRACK>
 __global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
 k_sweep_y(sweep_args a)
 {
+    if (!sweep_begin(a)) return;
     constexpr int LAG = PIPE::LAG;
     constexpr int PF = ARMON_Y_PF;   // rows in flight per lane, ahead of the march
     const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
@@ -393,6 +414,7 @@ template <class PIPE, bool TRACK>
 __global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
 k_sweep_y2(sweep_args a)
 {
+    if (!sweep_begin(a)) return;
     constexpr int LAG = PIPE::LAG;
     constexpr int PF = ARMON_Y_PF;   // rows in flight per lane, ahead of the march
     const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
@@ -707,6 +729,7 @@ template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK,
 __global__ void __launch_bounds__(64 * kXSRows, ARMON_XS_WAVES)
 k_sweep_x_dpp(sweep_args a, int niter)
 {
+    if (!sweep_begin(a)) return;
     sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK, SINGLE, ROW>(a, niter);
 }
 
@@ -1292,6 +1315,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.E_out = d->E_out;
     a.p_out = d->p_out;
     a.c_out = d->c_out;
+    a.st = d->dt_state;
     if (X) {
         a.seg = 512;
     } else if (ctx->tune_y_seg > 0) {
@@ -1344,7 +1368,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
                   d->eos == ARMON_EOS_PERFECT_GAS && d->x_kernel == 0, "headline-only variant build");
     rc = dispatch_exact<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD, ARMON_PROJECTION_EULER_2ND, ARMON_EOS_PERFECT_GAS>(ctx, a, d->axis, exact, track, &n_blocks);
     if (rc != ARMON_OK || !track) return rc;
-    return fold_dt_launch(ctx, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
+    return fold_dt_launch(ctx, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate, d->dt_state);
 #else
     if (d->scheme == ARMON_SCHEME_GODUNOV) {
         rc = dispatch_proj<ARMON_SCHEME_GODUNOV, ARMON_LIMITER_NONE>(ctx, a, d->axis, d->eos, d->projection, exact, track, &n_blocks);
@@ -1361,7 +1385,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
         }
     }
     if (rc != ARMON_OK || !track) return rc;
-    return fold_dt_launch(ctx, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate);
+    return fold_dt_launch(ctx, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate, d->dt_state);
 #endif
 }
 

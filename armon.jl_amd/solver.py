@@ -716,8 +716,181 @@ def solver_cycle(params, grid, last_cycle=True):
     return False
 
 
+# ---- graph replay of the cycle (device-resident time step) ----------------------------------------------------------------
+GRAPH_BATCH = 8            # cycles enqueued between two looks at the device state
+GRAPH_EVENT_SLOT = 1014    # event-pool slots 1014, 1015
+
+
+def graph_cycles_usable(params):
+    """The cycle can be captured once and replayed when nothing on the host has to happen inside it: one block, fused
+    sweeps, no per-cycle output (conservation print-outs, animation frames, step comparisons)."""
+    if not (params.use_fused_sweep and getattr(params, "graph_cycles", False)):
+        return False
+    if params.use_MPI or any(n != PROC_NULL for n in params.neighbours.values()):
+        return False
+    return params.silent > 1 and params.animation_step == 0 and not params.compare and not params.kernel_callbacks
+
+
+def _graph_sweep_descs(params, grid, cycle_parity, state_ptr):
+    """Descriptors of one cycle's sweeps with the time step read from the device state (dt = the split factor)."""
+    descs = []
+    sweeps = split_axes(params.axis_splitting, cycle_parity)
+    for k, (axis, dt_factor) in enumerate(sweeps):
+        last = k == len(sweeps) - 1
+        d = sweep_desc(params, grid, axis, float(params.T(dt_factor)), params.cell_size(int(axis) - 1),
+                       emit_p=last, emit_dt=last and not params.cst_dt)
+        d.dt_state = state_ptr
+        descs.append(d)
+        grid.swap_state()
+    return descs
+
+
+def time_loop_graph(params, grid, _after_handover=None):
+    """The time loop with the dt state machine on the device and each cycle replayed from a hipGraph
+    (include/armon_hip.h: armon_dt_state, armon_hip_dt_state_step, armon_hip_graph_*). Cycles 0 and 1 run host-driven as
+    in ``time_loop`` — cycle 0 needs the staged dtCFL kernel, and everything a capture records must have run once —, then the
+    device owns (cycle, time, current_dt): a cycle is ONE host call, the host reads the state back every GRAPH_BATCH
+    cycles without stopping the stream. Same bits, same cycle count, same final time as the host-driven loop (tests)."""
+    dev, gdt, T = params.device, grid.global_dt, params.T
+    gdt.reset()
+    grid.dt_inflight.clear()
+    params.wait()
+    t1 = _time.perf_counter_ns()
+    maxtime = T(params.maxtime)
+
+    def ends():
+        if params.cst_dt:
+            return T(gdt.time + gdt.current_dt) >= maxtime or gdt.cycle + 1 >= params.maxcycle
+        return gdt.cycle + 1 >= params.maxcycle or gdt.current_dt == 0 or T(gdt.time + gdt.current_dt) >= maxtime
+
+    # host-driven start: cycles 0 and 1 (the second one consumes the first deferred CFL step)
+    while gdt.time < maxtime and gdt.cycle < params.maxcycle and gdt.cycle < 2:
+        if solver_cycle(params, grid, last_cycle=ends()):
+            break
+        gdt.next_cycle()
+    n_parities = 1 if params.axis_splitting in ("Sequential", "X_only", "Y_only") else 2
+    swaps_per_cycle = len(split_axes(params.axis_splitting, 0))
+    if gdt.time < maxtime and gdt.cycle < params.maxcycle:
+        # hand the state machine over: the CFL step of the state cycle `gdt.cycle` starts from was posted by the previous one
+        L_prev = 0.0
+        if not params.cst_dt:
+            L_prev = take_dt_readback(params, grid, gdt.cycle - 1)
+        # auto_step: the fold of the last sweep's dt reduction steps the state machine itself (one kernel less per cycle);
+        # with a constant time step there is no reduction to ride on and the step stays a kernel of its own
+        auto = not params.cst_dt
+        st = _lib.DtState(current_dt=float(gdt.current_dt), time=float(gdt.time), L_prev=float(L_prev), cycle=gdt.cycle,
+                          done=0, invalid=0, emit_p=int(ends()), auto_step=int(auto), cst_dt=int(params.cst_dt),
+                          maxcycle=params.maxcycle, cfl=float(params.cfl), maxtime=float(params.maxtime), Dt=float(params.Dt))
+        state = dev.empty(C.sizeof(_lib.DtState) // 8, np.float64)
+        host_state = dev.pinned(C.sizeof(_lib.DtState) // 8 * 2, np.float64)
+        check(dev._L.armon_hip_memcpy(dev.ctx, C.c_void_p(state.ptr), C.byref(st), C.sizeof(st), 1))
+        step = params.fn("dt_state_step")
+        L_new = C.c_void_p(grid.dt_scalar.ptr)
+        # the step kernel runs once outside any capture, on a state that is already `done` (a no-op)
+        dummy = dev.empty(C.sizeof(_lib.DtState) // 8, np.float64)
+        over = _lib.DtState(done=1)
+        check(dev._L.armon_hip_memcpy(dev.ctx, C.c_void_p(dummy.ptr), C.byref(over), C.sizeof(over), 1))
+        check(step(dev.ctx, C.c_void_p(dummy.ptr), L_new, float(params.cfl), float(params.maxtime), params.maxcycle,
+                   int(params.cst_dt), float(params.Dt)))
+        params.wait()
+        dummy.free()
+
+        def enqueue_cycle(parity):
+            for d in _graph_sweep_descs(params, grid, parity, state.ptr):
+                check(params.fn("sweep")(dev.ctx, C.byref(d)))
+            if not auto:
+                check(step(dev.ctx, C.c_void_p(state.ptr), L_new, float(params.cfl), float(params.maxtime), params.maxcycle,
+                           int(params.cst_dt), float(params.Dt)))
+
+        # One graph per cycle parity, and per parity of the ping-pong (a cycle of an odd number of sweeps leaves the state in
+        # the other set of vectors): captured lazily, keyed by (parity of the cycle, which set holds the state).
+        graphs, origin = {}, grid.data["rho"].ptr
+
+        def launch_cycle(cycle):
+            key = (cycle % n_parities, grid.data["rho"].ptr == origin)
+            if key not in graphs:
+                check(dev._L.armon_hip_graph_begin(dev.ctx))
+                try:
+                    enqueue_cycle(cycle)
+                finally:
+                    g = C.c_void_p()
+                    rc = dev._L.armon_hip_graph_end(dev.ctx, C.byref(g))
+                check(rc)
+                graphs[key] = g
+                # the capture only recorded the cycle: undo its ping-pong bookkeeping, then replay it for real below
+                for _ in range(swaps_per_cycle):
+                    grid.swap_state()
+            check(dev._L.armon_hip_graph_launch(dev.ctx, graphs[key]))
+            for _ in range(swaps_per_cycle):
+                grid.swap_state()
+
+        def read_state(slot):
+            check(dev._L.armon_hip_memcpy_async(dev.ctx, C.c_void_p(host_state.ptr + slot * C.sizeof(_lib.DtState)),
+                                               C.c_void_p(state.ptr), C.sizeof(_lib.DtState), 2))
+            dev.event_record(GRAPH_EVENT_SLOT + slot)
+
+        def state_at(slot):
+            dev.event_sync(GRAPH_EVENT_SLOT + slot)
+            return _lib.DtState.from_buffer_copy(bytes(host_state.array.view(np.uint8)[slot * C.sizeof(_lib.DtState):
+                                                                                       (slot + 1) * C.sizeof(_lib.DtState)]))
+
+        # Replay. The host does not know which cycle is the last one: it enqueues batches and looks at the state of the
+        # PREVIOUS batch while the current one runs; cycles enqueued past the end are no-ops on the device (`done`), but
+        # the ping-pong bookkeeping above assumed they ran, so the final state's set is recomputed from the cycle count.
+        if _after_handover is not None:        # test hook: the device owns the time step from here on
+            _after_handover(params, grid)
+        cycle, batch, final = gdt.cycle, 0, None
+        start_cycle, start_in_origin = gdt.cycle, grid.data["rho"].ptr == origin
+        try:
+            while final is None:
+                for _ in range(GRAPH_BATCH):
+                    launch_cycle(cycle)
+                    cycle += 1
+                read_state(batch & 1)
+                if batch > 0:
+                    prev = state_at((batch - 1) & 1)
+                    if prev.done:
+                        final = prev
+                batch += 1
+                if final is None and cycle - start_cycle > params.maxcycle + 2 * GRAPH_BATCH:
+                    final = state_at((batch - 1) & 1)
+            last = state_at((batch - 1) & 1)
+            final = last if last.done else final
+        finally:
+            params.wait()
+            for g in graphs.values():
+                dev._L.armon_hip_graph_destroy(g)
+            state.free()
+        if final.invalid:
+            host_state.free()
+            solver_error("time", f"Invalid time step for cycle {final.invalid_cycle}: {final.invalid_value}")
+        # where the state really is: cycles [start_cycle, final.cycle) ran, the later ones were no-ops
+        ran = final.cycle - start_cycle
+        in_origin = start_in_origin if (ran * swaps_per_cycle) % 2 == 0 else not start_in_origin
+        if (grid.data["rho"].ptr == origin) != in_origin:
+            grid.swap_state()
+        gdt.cycle, gdt.time, gdt.current_dt = int(final.cycle), T(final.time), T(final.current_dt)
+        grid.graph_report = {"graphs": len(graphs), "cycles_replayed": int(ran), "cycles_enqueued": cycle - start_cycle}
+        host_state.free()
+    params.wait()
+    t2 = _time.perf_counter_ns()
+    solve_time = t2 - t1
+    cells = params.N[0] * params.N[1]
+    grind_time = solve_time / max(gdt.cycle * cells, 1)
+    if params.is_root and params.silent < 3:
+        print(" ")
+        print(f"Total time:  {solve_time / 1e9:.5f} sec")
+        print(f"Grind time:  {grind_time / 1e3:.5f} µs/cell/cycle")
+        print(f"Cells/sec:   {1 / grind_time * 1e3:.5f} Mega cells/sec")
+        print(f"Cycles:      {gdt.cycle}")
+        print(f"Last cycle:  {gdt.time:.18f} sec, Δt={gdt.current_dt:.18f} sec")
+    return float(gdt.time), float(gdt.current_dt), gdt.cycle, 1 / grind_time, solve_time
+
+
 def time_loop(params, grid):
     """ref src/solver.jl:323-403 → (time, dt, cycles, cells_per_ns, solve_time_ns)"""
+    if graph_cycles_usable(params):
+        return time_loop_graph(params, grid)
     grid.global_dt.reset()
     grid.dt_inflight.clear()
     gdt = grid.global_dt

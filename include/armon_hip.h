@@ -260,6 +260,7 @@ ARMON_API int armon_hip_init_test_f32(armon_ctx*, armon_range, int test, int64_t
  * (ρ,u,v,E) from `in` and writing them to `out` (ping-pong; `in` and `out` must not alias).
  * Algorithmic traffic 64 B per real cell. Optionally materialises p (saved_vars, ref
  * src/blocking/blocks.jl:49) and the per-cell CFL minimum for the next cycle. */
+struct armon_dt_state;       /* the time-step state on the device, defined below */
 typedef struct {
     int32_t axis;            /* ARMON_AXIS_X / _Y                                               */
     int32_t scheme;          /* ARMON_SCHEME_*                                                  */
@@ -297,9 +298,56 @@ typedef struct {
     int64_t out_lo, out_hi;
     int32_t dt_accumulate;
     int32_t reserved;
+    /* Device-resident time step (armon_dt_state below), or NULL. When set, the sweep reads the cycle's time step from
+     * device memory — its step is `dt` (then a FACTOR: 1, or 0.5 for Strang's half sweeps) x dt_state->current_dt —, does
+     * nothing at all once dt_state->done is set, and writes p_out only when dt_state->emit_p is set: what lets a whole
+     * cycle be captured once in a hipGraph and replayed without the host reading a scalar (armon_hip_graph_*). */
+    struct armon_dt_state* dt_state;
 } armon_sweep_desc;
 
 ARMON_API int armon_hip_sweep(armon_ctx*, const armon_sweep_desc*);
+
+/* ---- the dt state machine on the device + graph replay of a cycle -------------------------------------------------------- */
+/* GlobalTimeStep (ref src/solver_state.jl:30-166) in device memory: update_dt! (:102-142: validity check, cfl scaling, the
+ * 1.05 cap) and next_cycle! (:145-166) run as a one-thread kernel after the last sweep of a cycle, so that a cycle —
+ * sweeps, dt reduction, state update, the time_loop's exit test (ref src/solver.jl:350) — has no host-read scalar and can
+ * be replayed from a hipGraph. Values are stored as doubles; an fp32 run computes them in float (the _f32 step) exactly as
+ * the reference's GlobalTimeStep{Float32} does. */
+typedef struct armon_dt_state {
+    double  current_dt;      /* time step of the cycle about to run / running                                        */
+    double  time;            /* physical time at the start of that cycle                                            */
+    double  L_prev;          /* CFL step of the state that cycle starts from (reduced by the previous cycle's last sweep) */
+    int64_t cycle;
+    int32_t done;            /* the time loop is over (time >= maxtime, cycle >= maxcycle, or an invalid step): sweeps and steps are no-ops */
+    int32_t invalid;         /* a non-finite or non-positive step was seen (ref :123-124), at cycle `invalid_cycle`  */
+    int32_t emit_p;          /* the cycle about to run is the last one: its last sweep materialises p               */
+    int32_t pad;
+    int64_t invalid_cycle;
+    double  invalid_value;
+    /* auto_step != 0: the fold of a sweep's fused dt reduction (dt_cfl_out with dt_state set, dt_accumulate == 0) performs
+     * the state-machine step itself, with the constants below — one kernel less per replayed cycle than a separate
+     * armon_hip_dt_state_step (a small grid's cycle time is its number of dependent launches). */
+    int32_t auto_step, cst_dt;
+    int64_t maxcycle;
+    double  cfl, maxtime, Dt;
+} armon_dt_state;
+
+/* One state-machine step on the context's stream, after the last sweep of a cycle whose dt_cfl_out was `L_new_dev`:
+ * next_cycle_dt = min(cfl x L_prev, 1.05 x current_dt) (or Dt with cst_dt), cycle += 1, time += current_dt,
+ * current_dt = next_cycle_dt, L_prev = *L_new_dev, then done / emit_p for the next cycle from maxtime and maxcycle. */
+ARMON_API int armon_hip_dt_state_step(armon_ctx*, armon_dt_state* state_dev, const double* L_new_dev, double cfl,
+                                      double maxtime, int64_t maxcycle, int cst_dt, double Dt);
+ARMON_API int armon_hip_dt_state_step_f32(armon_ctx*, armon_dt_state* state_dev, const float* L_new_dev, double cfl,
+                                          double maxtime, int64_t maxcycle, int cst_dt, double Dt);
+
+/* Stream capture of whatever the caller enqueues on the context's stream between _begin and _end (sweeps with dt_state,
+ * the state step) into an executable graph; _launch replays it on that stream. Everything captured must already have run
+ * once outside a capture (the library sizes its scratch on first use and cannot allocate while capturing). */
+typedef struct armon_graph armon_graph;
+ARMON_API int armon_hip_graph_begin(armon_ctx*);
+ARMON_API int armon_hip_graph_end(armon_ctx*, armon_graph** graph);
+ARMON_API int armon_hip_graph_launch(armon_ctx*, armon_graph* graph);
+ARMON_API int armon_hip_graph_destroy(armon_graph* graph);
 
 /* Whole cycle in one launch (Sequential splitting: X sweep, then Y sweep — ref src/solver.jl:300-316 executed twice)
  * over one block: reads (rho,u,v,E) of x_desc->*_in ONCE and writes y_desc->*_out ONCE; the state between the two
@@ -354,6 +402,7 @@ typedef struct {
     double  cfl_dx, cfl_dy;
     int64_t out_lo, out_hi;
     int32_t dt_accumulate, reserved;
+    struct armon_dt_state* dt_state;
 } armon_sweep_desc_f32;
 
 ARMON_API int armon_hip_sweep_f32(armon_ctx*, const armon_sweep_desc_f32*);

@@ -235,6 +235,7 @@ struct SweepDesc{T}      # == armon_sweep_desc / armon_sweep_desc_f32, include/a
     p_out::Ptr{T}; c_out::Ptr{T}
     dt_cfl_out::Ptr{T}; cfl_dx::Float64; cfl_dy::Float64
     out_lo::Int64; out_hi::Int64; dt_accumulate::Cint; reserved::Cint
+    dt_state::Ptr{Cvoid}     # armon_dt_state on the device (graph replay of a cycle), or C_NULL: dt above is the time step itself
 end
 
 scheme_tag(::Armon.RiemannGodunov) = Cint(0); scheme_tag(::Armon.RiemannGAD) = Cint(1)
@@ -282,7 +283,7 @@ function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::Fus
         pointer(d.ρ), pointer(d.u), pointer(d.v), pointer(d.E),
         pointer(alt[1]), pointer(alt[2]), pointer(alt[3]), pointer(alt[4]),
         emit_p ? pointer(d.p) : Ptr{T}(C_NULL), Ptr{T}(C_NULL),
-        emit_dt ? dt_out : Ptr{T}(C_NULL), Δ[1], Δ[2], out[1], out[2], 0, 0))
+        emit_dt ? dt_out : Ptr{T}(C_NULL), Δ[1], Δ[2], out[1], out[2], 0, 0, C_NULL))
     GC.@preserve d alt check(ccall(fn(:armon_hip_sweep, T), Cint, (Ptr{Cvoid}, Ptr{SweepDesc{T}}), ctx, desc))
     swap && swap_state!(blk, fs)
 end

@@ -1,0 +1,154 @@
+"""Graph replay of the cycle with the dt state machine on the device (armon_dt_state, armon_hip_dt_state_step,
+armon_hip_graph_*; host: solver.time_loop_graph, option graph_cycles=True): the same bits, cycle count, final time and last
+dt as the host-driven time loop (ref src/solver.jl:323-403, src/solver_state.jl:102-166), whichever of maxtime / maxcycle
+ends the run, for every splitting, both EOS, both arithmetics, fp32, constant dt — and the invalid-step error."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def both(test, N, **o):
+    import armon_amd
+    out = []
+    for graph in (False, True):
+        params = armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True, graph_cycles=graph, **o)
+        stats = armon_amd.armon(params)
+        host = stats.data.device_to_host(("rho", "u", "v", "E", "p"))
+        out.append((stats, {k: stats.data.real_view(v).copy() for k, v in host.items()}))
+    return out
+
+
+@pytest.mark.parametrize("test,N,opts", [
+    ("Sod", (100, 100), {}),                                                   # ends on maxtime (45 cycles), the golden run
+    ("Sod_circ", (67, 41), dict(maxcycle=37)),                                 # ends on maxcycle, not a multiple of the batch
+    ("Sod_circ", (67, 41), dict(maxcycle=3)),                                  # the graph part runs a single cycle
+    ("Sod_circ", (64, 48), dict(maxcycle=2)),                                  # never reaches the graph part
+    ("Bizarrium", (96, 32), dict(maxcycle=30)),
+    ("Sedov", (50, 50), dict(maxcycle=41)),
+    ("Sod_circ", (80, 56), dict(maxcycle=26, axis_splitting="Godunov")),       # two graphs (cycle parity)
+    ("Sod_circ", (80, 56), dict(maxcycle=27, axis_splitting="Strang")),        # three sweeps: the ping-pong parity alternates
+    ("Sod", (96, 8), dict(maxcycle=25, axis_splitting="X_only")),
+    ("Sod_y", (8, 96), dict(maxcycle=24, axis_splitting="Y_only")),
+    ("Sod_circ", (48, 48), dict(maxcycle=30, scheme="Godunov", projection="euler", nghost=2)),
+    ("Sod_circ", (64, 64), dict(maxcycle=33, cst_dt=True, Dt=1e-4)),
+    ("Sod_circ", (64, 64), dict(maxtime=0.004, cst_dt=True, Dt=3e-4)),
+    ("Sod", (200, 20), dict(maxtime=0.05)),
+])
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+def test_graph_replay_equals_the_host_driven_loop(test, N, opts, exact):
+    (s0, f0), (s1, f1) = both(test, N, exact_arithmetic=exact, **opts)
+    assert s1.cycles == s0.cycles and s1.final_time == s0.final_time and s1.last_dt == s0.last_dt
+    for k in f0:
+        assert np.array_equal(f1[k], f0[k]), k
+
+
+@pytest.mark.parametrize("test,N,opts", [("Sod_circ", (67, 41), dict(maxcycle=37)), ("Sod", (100, 100), {}),
+                                         ("Bizarrium", (64, 32), dict(maxcycle=20, axis_splitting="Strang"))])
+def test_graph_replay_f32(test, N, opts):
+    (s0, f0), (s1, f1) = both(test, N, data_type="float32", **opts)
+    assert s1.cycles == s0.cycles and s1.final_time == s0.final_time and s1.last_dt == s0.last_dt
+    for k in f0:
+        assert np.array_equal(f1[k], f0[k]), k
+
+
+def test_graph_replay_matches_the_golden_and_the_oracle(oracle):
+    from conftest import load_golden
+    import armon_amd
+    g = load_golden("Sod_circ")
+    params = armon_amd.ArmonParameters(test="Sod_circ", N=(100, 100), silent=5, return_data=True, graph_cycles=True,
+                                       exact_arithmetic=True)
+    stats = armon_amd.armon(params)
+    orun, f = oracle.solve(test="Sod_circ", N=(100, 100))
+    assert stats.cycles == int(g["cycles"]) == orun.cycles and stats.last_dt == orun.last_dt and stats.final_time == orun.final_time
+    host = stats.data.device_to_host(("rho", "u", "v", "E", "p"))
+    for k in ("rho", "u", "v", "E", "p"):
+        assert np.array_equal(stats.data.real_view(host[k]), oracle.real_view(f[k], 100, 100, 4)), k
+
+
+def test_graph_replay_reports_an_invalid_time_step():
+    """One cell goes bad after the hand-over to the device: the state machine stops the loop at the first non-finite CFL step
+    and the host raises SolverException(:time) (ref src/solver_state.jl:123-124) instead of replaying NaNs to maxcycle."""
+    import armon_amd
+    from armon_amd import solver as S
+    params = armon_amd.ArmonParameters(test="Sod_circ", N=(96, 64), maxcycle=100000, silent=5, graph_cycles=True)
+    grid = S.BlockGrid(params)
+    S.init_test(params, grid)
+
+    def poison(params, grid):
+        g = params.nghost
+        a = grid.data["E"].to_host()
+        a.reshape(params.block_size.size[1], params.block_size.size[0])[g + 30, g + 40] = -1.0
+        grid.data["E"].copy_from_host(a)
+
+    with pytest.raises(armon_amd.SolverException) as e:
+        S.time_loop_graph(params, grid, _after_handover=poison)
+    assert e.value.category == "time" and "cycle 3" in e.value.msg or "cycle 4" in e.value.msg, e.value.msg
+
+
+def test_dt_state_step_follows_update_dt_and_next_cycle():
+    """The one-thread kernel against the host's GlobalTimeStep (ref src/solver_state.jl:102-166) through the C ABI."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.device import HIPDevice
+    from armon_amd.solver import GlobalTimeStep
+    dev = HIPDevice(0)
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for dtype, suffix in ((np.float64, ""), (np.float32, "_f32")):
+        params = armon_amd.ArmonParameters(test="Sod", N=(16, 16), silent=5, data_type=dtype, maxtime=0.01, maxcycle=60)
+        T = params.T
+        gdt = GlobalTimeStep(params)
+        gdt.cycle, gdt.time, gdt.current_dt = 2, T(3e-4), T(1.5e-4)
+        L_prev = T(2.1e-4)
+        st = _lib.DtState(current_dt=float(gdt.current_dt), time=float(gdt.time), L_prev=float(L_prev), cycle=2)
+        state = dev.empty(C.sizeof(st) // 8, np.float64)
+        _lib.check(L.armon_hip_memcpy(dev.ctx, C.c_void_p(state.ptr), C.byref(st), C.sizeof(st), 1))
+        scalar = dev.empty(2, dtype)
+        for _ in range(70):
+            L_new = T(rng.uniform(0.5e-4, 4e-4))
+            scalar.copy_from_host(np.array([L_new, 0], dtype=dtype))
+            _lib.check(getattr(L, "armon_hip_dt_state_step" + suffix)(dev.ctx, C.c_void_p(state.ptr), C.c_void_p(scalar.ptr),
+                                                                        float(params.cfl), float(params.maxtime), params.maxcycle, 0, 0.0))
+            got = _lib.DtState.from_buffer_copy(state.to_host().tobytes())
+            over = not (gdt.time < T(params.maxtime) and gdt.cycle < params.maxcycle)
+            if not over:
+                gdt.update_dt(L_prev)
+                gdt.next_cycle()
+                L_prev = L_new
+            assert got.cycle == gdt.cycle and got.time == float(gdt.time) and got.current_dt == float(gdt.current_dt), (dtype, got.cycle)
+            now_over = not (gdt.time < T(params.maxtime) and gdt.cycle < params.maxcycle)
+            assert bool(got.done) == now_over
+            if not now_over:
+                ends = gdt.cycle + 1 >= params.maxcycle or T(gdt.time + gdt.current_dt) >= T(params.maxtime)
+                assert bool(got.emit_p) == bool(ends)
+        assert got.done and not got.invalid
+        # a NaN, an infinite and a negative CFL step stop the machine and are reported
+        for bad in (np.nan, np.inf, -1e-4):
+            st = _lib.DtState(current_dt=1e-4, time=0.0, L_prev=float(T(bad)), cycle=7)
+            _lib.check(L.armon_hip_memcpy(dev.ctx, C.c_void_p(state.ptr), C.byref(st), C.sizeof(st), 1))
+            _lib.check(getattr(L, "armon_hip_dt_state_step" + suffix)(dev.ctx, C.c_void_p(state.ptr), C.c_void_p(scalar.ptr),
+                                                                        0.5, 1.0, 1000, 0, 0.0))
+            got = _lib.DtState.from_buffer_copy(state.to_host().tobytes())
+            assert got.done == 1 and got.invalid == 1 and got.invalid_cycle == 7 and got.cycle == 7
+    dev.close()
+
+
+def test_graph_replay_really_replays():
+    import armon_amd
+    params = armon_amd.ArmonParameters(test="Sod_circ", N=(80, 56), maxcycle=27, axis_splitting="Strang", silent=5,
+                                       return_data=True, graph_cycles=True)
+    stats = armon_amd.armon(params)
+    rep = stats.data.graph_report
+    assert rep["graphs"] == 2 and rep["cycles_replayed"] == 25 and stats.cycles == 27 and rep["cycles_enqueued"] >= 25
+
+
+def test_graph_mode_is_refused_where_the_host_must_act_inside_a_cycle(tmp_path):
+    """Per-cycle output needs the host inside the cycle: the option then falls back to the host-driven loop (same result)."""
+    import armon_amd
+    from armon_amd.solver import graph_cycles_usable
+    assert graph_cycles_usable(armon_amd.ArmonParameters(test="Sod", N=(32, 32), silent=5, graph_cycles=True))
+    for o in (dict(silent=1), dict(animation_step=2, output_dir=str(tmp_path)), dict(use_fused_sweep=False), dict(graph_cycles=False)):
+        kw = dict(dict(silent=5, graph_cycles=True), **o)
+        assert not graph_cycles_usable(armon_amd.ArmonParameters(test="Sod", N=(32, 32), **kw))
