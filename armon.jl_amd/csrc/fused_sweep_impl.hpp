@@ -437,7 +437,10 @@ k_sweep_y2(sweep_args a)
     const rsrc_t w_rho = make_rsrc(a.rho_out + out_base), w_ua = make_rsrc(a.ua_out + out_base);
     const rsrc_t w_ut = make_rsrc(a.ut_out + out_base), w_E = make_rsrc(a.E_out + out_base);
 
-    PIPE pipe[2] = {PIPE(a.dt, a.dx, a.gamma), PIPE(a.dt, a.dx, a.gamma)};
+    // the two columns of a lane are ONE pipeline on 2-vectors: packed v_pk_* arithmetic (sweep_pipeline.hpp, float2v)
+    using V = fused::fast::float2v;
+    using PIPEV = fused::PipeFast<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, V>;
+    PIPEV pipe(a.dt, a.dx, a.gamma);
     cfl_track cfl;
 
     int lj = jb;                     // next row to load and its offset from the run's first row
@@ -450,15 +453,13 @@ k_sweep_y2(sweep_args a)
     auto load = [&](auto slot, auto checked) {
         constexpr int K = decltype(slot)::value & 7;
         constexpr bool CHECKED = decltype(checked)::value;
-        auto& d0 = pipe[0].c[K];
-        auto& d1 = pipe[1].c[K];
+        auto& dst = pipe.c[K];
+        auto vec = [](float2 q) { return V{q.x, q.y}; };
         auto put = [&](unsigned off, real fa, real ft) {
-            const float2 r = buf_load2(r_rho, colb, off), u = buf_load2(r_ua, colb, off);
-            const float2 v = buf_load2(r_ut, colb, off), e = buf_load2(r_E, colb, off);
-            d0.rho = r.x; d1.rho = r.y;
-            d0.ua = u.x * fa; d1.ua = u.y * fa;
-            d0.ut = v.x * ft; d1.ut = v.y * ft;
-            d0.E = e.x; d1.E = e.y;
+            dst.rho = vec(buf_load2(r_rho, colb, off));
+            dst.ua = vec(buf_load2(r_ua, colb, off)) * fa;
+            dst.ut = vec(buf_load2(r_ut, colb, off)) * ft;
+            dst.E = vec(buf_load2(r_E, colb, off));
         };
         if (CHECKED) {
             const bool m_lo = lj < 0 && a.bc_low, m_hi = lj >= ny && a.bc_high;     // uniform, rare
@@ -473,12 +474,10 @@ k_sweep_y2(sweep_args a)
                 lo_off += pitchb;
             }
         } else {
-            const float2 r = buf_load2(r_rho, colb, lo_off), u = buf_load2(r_ua, colb, lo_off);
-            const float2 v = buf_load2(r_ut, colb, lo_off), e = buf_load2(r_E, colb, lo_off);
-            d0.rho = r.x; d1.rho = r.y;
-            d0.ua = u.x; d1.ua = u.y;
-            d0.ut = v.x; d1.ut = v.y;
-            d0.E = e.x; d1.E = e.y;
+            dst.rho = vec(buf_load2(r_rho, colb, lo_off));
+            dst.ua = vec(buf_load2(r_ua, colb, lo_off));
+            dst.ut = vec(buf_load2(r_ut, colb, lo_off));
+            dst.E = vec(buf_load2(r_E, colb, lo_off));
             lj++;
             lo_off += pitchb;
         }
@@ -488,34 +487,32 @@ k_sweep_y2(sweep_args a)
         constexpr int PH8 = decltype(ph)::value;
         constexpr bool CHECKED = decltype(checked)::value;
         load(integral_constant<int, PH8 + PF>{}, checked);   // row j + PF → slot (j + PF) mod 8
-        real p0, c0, cl0, p1, c1, cl1;
+        V p, c, c_lag;
 #ifdef ARMON_PROBE_NOCOMPUTE   // calibration build: same loads/stores, no arithmetic (tools/build_variant.sh)
-        p0 = c0 = cl0 = p1 = c1 = cl1 = 0;
-        const auto& cc0 = pipe[0].c[PH8 & 7];
-        const auto& cc1 = pipe[1].c[PH8 & 7];
-        const fused::Out4<real> out0{cc0.rho, cc0.ua, cc0.ut, cc0.E}, out1{cc1.rho, cc1.ua, cc1.ut, cc1.E};
+        p = c = c_lag = V(0.f);
+        const auto& cc = pipe.c[PH8 & 7];
+        const fused::Out4<V> out{cc.rho, cc.ua, cc.ut, cc.E};
 #else
-        const fused::Out4<real> out0 = pipe[0].template advance<true, PH8>(p0, c0, cl0);
-        const fused::Out4<real> out1 = pipe[1].template advance<true, PH8>(p1, c1, cl1);
+        const fused::Out4<V> out = pipe.template advance<true, PH8>(p, c, c_lag);
 #endif
         const int o = j - LAG;
         if (CHECKED) {
             if (a.emit && j >= o0 && j < o1 && active) {
                 const unsigned off = so_off + LAG * pitchb;
-                if (a.emit & 1) buf_store2(make_rsrc(a.p_out + out_base), colb, off, p0, p1);
-                if (a.emit & 2) buf_store2(make_rsrc(a.c_out + out_base), colb, off, c0, c1);
+                if (a.emit & 1) buf_store2(make_rsrc(a.p_out + out_base), colb, off, p.x, p.y);
+                if (a.emit & 2) buf_store2(make_rsrc(a.c_out + out_base), colb, off, c.x, c.y);
             }
         }
         if (!CHECKED || (o >= o0 && o < o1)) {
             if (active) {
-                buf_store2(w_rho, colb, so_off, out0.rho, out1.rho);
-                buf_store2(w_ua, colb, so_off, out0.ua, out1.ua);
-                buf_store2(w_ut, colb, so_off, out0.ut, out1.ut);
-                buf_store2(w_E, colb, so_off, out0.E, out1.E);
+                buf_store2(w_rho, colb, so_off, out.rho.x, out.rho.y);
+                buf_store2(w_ua, colb, so_off, out.ua.x, out.ua.y);
+                buf_store2(w_ut, colb, so_off, out.ut.x, out.ut.y);
+                buf_store2(w_E, colb, so_off, out.E.x, out.E.y);
             }
             if (TRACK) {                                     // Y sweep: ut = u, ua = v
-                cfl.add(out0.ut, out0.ua, cl0);
-                cfl.add(out1.ut, out1.ua, cl1);
+                cfl.add(out.ut.x, out.ua.x, c_lag.x);
+                cfl.add(out.ut.y, out.ua.y, c_lag.y);
             }
         }
         so_off += pitchb;

@@ -268,6 +268,23 @@ __device__ __forceinline__ double sqrt_(double x)
 }
 __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }      // v_sqrt_f32: 1 ulp, no denormal scaling (operands are O(1) energies)
 
+// Two fp32 cells per lane as ONE 64-bit value (the tuned fp32 Y march, k_sweep_y2): elementwise arithmetic on this type is
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 — one instruction for both cells — where two scalar pipelines side by side
+// left the pairing to the compiler's SLP pass (which found about half of it and paid for the rest in v_mov shuffles).
+// Same IEEE operations per component, hence the same bits as the scalar pipeline.
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v rcp(float2v x) { return float2v{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ float2v rcp1(float2v x) { return rcp(x); }
+__device__ __forceinline__ float2v sqrt_(float2v x) { return float2v{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)}; }
+__device__ __forceinline__ float2v fma_(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float2v max_(float2v a, float2v b) { return float2v{__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ float2v min_(float2v a, float2v b) { return float2v{__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)}; }
+// component-wise choice; `m` is the result of a comparison (bool for a scalar, an integer vector for float2v)
+template <class M, class T> __device__ __forceinline__ T sel(M m, T a, T b) { return m ? a : b; }
+// the scalar type behind a working type: uniform parameters (dt, dx, γ …) stay scalars (SGPRs) next to vector state
+template <typename T> struct scalar_of { using type = T; };
+template <> struct scalar_of<float2v> { using type = float; };
+
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double max_(double a, double b) { return __builtin_fmax(a, b); }
@@ -335,7 +352,8 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     // Lagrangian state: q_* = ρ·(ua, ut, E); hinv = 0.5/dxl; d_* = q(this) - q(previous cell)
     struct Upd { T rho, q_ua, q_ut, q_E, dxl, hinv, d_rho, d_ua, d_ut, d_E; };
 
-    T dt, dx, gamma, inv_dx, dt_dx, gm1, ggm1;
+    using Sc = typename fast::scalar_of<T>::type;     // uniform parameters
+    Sc dt, dx, gamma, inv_dx, dt_dx, gm1, ggm1;
     Cell c[8];
     T gus[4], gps[4], src[4];          // first-order solutions + (rc_l + rc_r) of the interface
     T fps[4], dtu[4], pu[4];           // final flux: pˢ, dt·uˢ, pˢ·uˢ at interfaces nf .. nf-3
@@ -345,23 +363,23 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     T a[2][4];
     T csr[4];
 
-    __device__ __forceinline__ PipeFast(T dt_, T dx_, T gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
+    __device__ __forceinline__ PipeFast(Sc dt_, Sc dx_, Sc gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
     {
-        inv_dx = T(1.) / dx_;
+        inv_dx = Sc(1.) / dx_;
         dt_dx = dt_ / dx_;
-        gm1 = gamma_ - T(1.);
-        ggm1 = gamma_ * (gamma_ - T(1.));
+        gm1 = gamma_ - Sc(1.);
+        ggm1 = gamma_ * (gamma_ - Sc(1.));
 #pragma unroll
         for (int k = 0; k < 8; k++) c[k] = Cell{T(1.), T(0.), T(0.), T(1.), T(1.), T(1.)};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             gus[k] = T(0.); gps[k] = T(1.); src[k] = T(2.);
             fps[k] = T(1.); dtu[k] = T(0.); pu[k] = T(0.); csr[k] = T(1.);
-            l[k] = Upd{T(1.), T(0.), T(0.), T(1.), dx_, T(0.5) / dx_, T(0.), T(0.), T(0.), T(0.)};
+            l[k] = Upd{T(1.), T(0.), T(0.), T(1.), T(dx_), T(Sc(0.5) / dx_), T(0.), T(0.), T(0.), T(0.)};
             s[0][k] = s[1][k] = T(0.);
             a[0][k] = a[1][k] = T(0.);
         }
-        isum[0] = isum[1] = T(0.5) / dx_;
+        isum[0] = isum[1] = T(Sc(0.5) / dx_);
     }
 
     template <bool Y_AXIS, int PH8>
@@ -468,24 +486,25 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
             s[P0][3] = minmod(r_p * l0.d_E, r_m * l1.d_E);
             // interface is = cu-1
             const T disp = dtu[R2];
-            const bool up = disp > 0;
-            const Upd& d = up ? l2 : l1;
-            const T Dxe = up ? (dtu[R3] - dx) : (dx + dtu[R1]);
-            const T lf = Dxe * d.hinv;
-            const T q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
-            a[P0][0] = disp * fma_(-(up ? s[P1][0] : s[P0][0]), lf, d.rho);
-            a[P0][1] = disp * fma_(-(up ? s[P1][1] : s[P0][1]), lf, q1);
-            a[P0][2] = disp * fma_(-(up ? s[P1][2] : s[P0][2]), lf, q2);
-            a[P0][3] = disp * fma_(-(up ? s[P1][3] : s[P0][3]), lf, d.q_E);
+            const auto up = disp > T(0.);          // donor cell: cu-2 when the interface moves up, else cu-1 (per component)
+            const T Dxe = sel(up, dtu[R3] - dx, dx + dtu[R1]);
+            const T lf = Dxe * sel(up, l2.hinv, l1.hinv);
+            const T d_q1 = Y_AXIS ? sel(up, l2.q_ut, l1.q_ut) : sel(up, l2.q_ua, l1.q_ua);
+            const T d_q2 = Y_AXIS ? sel(up, l2.q_ua, l1.q_ua) : sel(up, l2.q_ut, l1.q_ut);
+            a[P0][0] = disp * fma_(-sel(up, s[P1][0], s[P0][0]), lf, sel(up, l2.rho, l1.rho));
+            a[P0][1] = disp * fma_(-sel(up, s[P1][1], s[P0][1]), lf, d_q1);
+            a[P0][2] = disp * fma_(-sel(up, s[P1][2], s[P0][2]), lf, d_q2);
+            a[P0][3] = disp * fma_(-sel(up, s[P1][3], s[P0][3]), lf, sel(up, l2.q_E, l1.q_E));
             return project<Y_AXIS, P0>(l2);
         } else {
             const T disp = dtu[R1];
-            const Upd& d = (disp > 0) ? l1 : l0;
-            const T q1 = Y_AXIS ? d.q_ut : d.q_ua, q2 = Y_AXIS ? d.q_ua : d.q_ut;
-            a[P0][0] = disp * d.rho;
-            a[P0][1] = disp * q1;
-            a[P0][2] = disp * q2;
-            a[P0][3] = disp * d.q_E;
+            const auto up = disp > T(0.);
+            const T d_q1 = Y_AXIS ? sel(up, l1.q_ut, l0.q_ut) : sel(up, l1.q_ua, l0.q_ua);
+            const T d_q2 = Y_AXIS ? sel(up, l1.q_ua, l0.q_ua) : sel(up, l1.q_ut, l0.q_ut);
+            a[P0][0] = disp * sel(up, l1.rho, l0.rho);
+            a[P0][1] = disp * d_q1;
+            a[P0][2] = disp * d_q2;
+            a[P0][3] = disp * sel(up, l1.q_E, l0.q_E);
             return project<Y_AXIS, P0>(l1);
         }
     }
