@@ -856,6 +856,9 @@ def time_loop_graph(params, grid, _after_handover=None):
                     final = state_at((batch - 1) & 1)
             last = state_at((batch - 1) & 1)
             final = last if last.done else final
+        except BaseException:
+            host_state.free()
+            raise
         finally:
             params.wait()
             for g in graphs.values():
