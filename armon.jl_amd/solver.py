@@ -857,6 +857,7 @@ def time_loop_graph(params, grid, _after_handover=None):
             last = state_at((batch - 1) & 1)
             final = last if last.done else final
         except BaseException:
+            params.wait()                 # no copy into the pinned slots is in flight any more
             host_state.free()
             raise
         finally:
