@@ -20,7 +20,14 @@ __device__ __forceinline__ int64_t row_base(const armon_range& r, int64_t j)
 
 // Outputs that the next kernel re-reads only after 2+ GB of other traffic (fluxes, advected quantities): streaming
 // stores, so that they do not displace the neighbour rows the stencils DO re-read from L2.
-template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+template <typename T> __device__ __forceinline__ void st_stream(T* p, T v)
+{
+#ifdef ARMON_ST_PLAIN            // A/B builds: ordinary stores
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
 
 // Threads are laid along a row of the range, shifted left so that every wave's row segment starts on a 64-B sector
 // of the array (ranges start g or g-w cells into a row: without the shift each 512-B segment straddles one more sector;
@@ -122,6 +129,10 @@ constexpr int kGadValid = 62;
 #define ARMON_GAD_ROWS 64        // rows per thread of the y form (tuning macro)
 #endif
 constexpr int kGadRows = ARMON_GAD_ROWS;
+#ifndef ARMON_GAD_AHEAD
+#define ARMON_GAD_AHEAD 1        // rows in flight ahead of the one being computed in the y form (tuning macro)
+#endif
+constexpr int kGadAhead = ARMON_GAD_AHEAD;
 
 template <int LIM, typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -145,17 +156,88 @@ k_acoustic_GAD_x(armon_range r, T dt, T dx, T* __restrict__ us, T* __restrict__ 
             if (has_cell) { rho_m = rho[i - 1]; c_m = c[i - 1]; u_m = u[i - 1]; p_m = p[i - 1]; }
         }
         T us_0, ps_0;
+#ifdef ARMON_GAD_NOCOMPUTE
+        us_0 = rho_m; ps_0 = c_m + u_m + p_m;
+#else
         phys::godunov(rho_i, rho_m, c_i, c_m, u_i, u_m, p_i, p_m, us_0, ps_0);        // interface i | i-1, once
+#endif
         const T us_m = from_prev_lane(us_0), ps_m = from_prev_lane(ps_0);
         const T us_p = from_next_lane(us_0), ps_p = from_next_lane(ps_0);
         T a, b;
+#ifdef ARMON_GAD_NOCOMPUTE       // probe builds: the kernel's memory pattern alone
+        a = rho_i + c_i + us_m * 0; b = u_i + p_i + us_p * 0;
+#else
         phys::gad_flux<LIM>(dt, dx, rho_m, c_m, u_m, p_m, rho_i, c_i, u_i, p_i, us_m, ps_m, us_0, ps_0, us_p, ps_p, a, b);
+#endif
         if (stores) {
             st_stream(us + i, a);
             st_stream(ps + i, b);
         }
     }
 }
+
+// Sweep along x, two cells per lane (fp64, even row pitch, 16-B aligned arrays): a wave covers a strip of 128 consecutive
+// cells with 16-B accesses and produces the 120 fluxes in its middle (4 halo cells on either side: the stencil needs 2 and 1,
+// but 120 cells are 15 whole 64-B sectors, so with the strip origins chosen below every strip's stores start and end on a
+// sector of the array, and its loads start 32 B before one — the layout of the fused X sweep). A workgroup
+// takes one strip of 4 consecutive rows. Same operands into the same functions as the forms above: the same bits.
+// Measured 2-3 % SLOWER than one cell per lane (2.42-2.44 against 2.37 ms at 16384², profiles/r03_gad_forms.txt): the kernel
+// runs at 95 % of its own no-arithmetic form either way, so the form is only compiled into A/B builds (-DARMON_GAD_X2=1).
+#ifndef ARMON_GAD_X2
+#define ARMON_GAD_X2 0
+#endif
+#if ARMON_GAD_X2
+constexpr int kGadStride2 = 120, kGadHalo2 = 4;
+
+template <int LIM>
+__global__ void __launch_bounds__(kBlock)
+k_acoustic_GAD_x2(armon_range r, double dt, double dx, double* __restrict__ us, double* __restrict__ ps,
+                  const double* __restrict__ rho, const double* __restrict__ u, const double* __restrict__ p,
+                  const double* __restrict__ c)
+{
+    using fused::from_next_lane;
+    using fused::from_prev_lane;
+    typedef double V2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // first flux of this strip, relative to the first cell of a row of the range (strip 0 starts on the sector at or below it)
+    const int64_t w0 = (int64_t)blockIdx.x * kGadStride2 - ((r.col_start + r.row_start) & 7);
+    const int64_t k0 = w0 - kGadHalo2 + 2 * lane;              // this lane's cells: k0, k0 + 1
+    const int64_t lo = w0 > 0 ? w0 : 0;
+    const int64_t hi = (w0 + kGadStride2 < r.row_len) ? w0 + kGadStride2 : r.row_len;
+    // reads stay inside the reference's stencil of the range: cells -2 .. row_len of a row
+    const bool in_a = k0 >= -2 && k0 <= r.row_len, in_b = k0 + 1 >= -2 && k0 + 1 <= r.row_len;
+    const bool st_a = k0 >= lo && k0 < hi, st_b = k0 + 1 >= lo && k0 + 1 < hi;
+    for (int64_t j = (int64_t)blockIdx.y * (kBlock / 64) + wave; j < r.col_len; j += (int64_t)gridDim.y * (kBlock / 64)) {
+        const int64_t i = row_base(r, j) + k0;
+        double rho_a = 1, c_a = 1, u_a = 0, p_a = 1, rho_b = 1, c_b = 1, u_b = 0, p_b = 1;
+        if (in_a && in_b) {
+            const V2 vr = *reinterpret_cast<const V2*>(rho + i), vc = *reinterpret_cast<const V2*>(c + i);
+            const V2 vu = *reinterpret_cast<const V2*>(u + i), vp = *reinterpret_cast<const V2*>(p + i);
+            rho_a = vr.x; rho_b = vr.y; c_a = vc.x; c_b = vc.y; u_a = vu.x; u_b = vu.y; p_a = vp.x; p_b = vp.y;
+        } else {
+            if (in_a) { rho_a = rho[i]; c_a = c[i]; u_a = u[i]; p_a = p[i]; }
+            if (in_b) { rho_b = rho[i + 1]; c_b = c[i + 1]; u_b = u[i + 1]; p_b = p[i + 1]; }
+        }
+        // the cell left of a is the previous lane's b (lane 0 reads zeros: its fluxes are halo)
+        const double rho_m = from_prev_lane(rho_b), c_m = from_prev_lane(c_b), u_m = from_prev_lane(u_b), p_m = from_prev_lane(p_b);
+        double us_a, ps_a, us_b, ps_b;
+        phys::godunov(rho_a, rho_m, c_a, c_m, u_a, u_m, p_a, p_m, us_a, ps_a);          // interface a | m
+        phys::godunov(rho_b, rho_a, c_b, c_a, u_b, u_a, p_b, p_a, us_b, ps_b);          // interface b | a
+        const double us_l = from_prev_lane(us_b), ps_l = from_prev_lane(ps_b);           // interface m | (cell before m)
+        const double us_r = from_next_lane(us_a), ps_r = from_next_lane(ps_a);           // interface (cell after b) | b
+        double fa_u, fa_p, fb_u, fb_p;
+        phys::gad_flux<LIM>(dt, dx, rho_m, c_m, u_m, p_m, rho_a, c_a, u_a, p_a, us_l, ps_l, us_a, ps_a, us_b, ps_b, fa_u, fa_p);
+        phys::gad_flux<LIM>(dt, dx, rho_a, c_a, u_a, p_a, rho_b, c_b, u_b, p_b, us_a, ps_a, us_b, ps_b, us_r, ps_r, fb_u, fb_p);
+        if (st_a && st_b) {
+            __builtin_nontemporal_store(V2{fa_u, fb_u}, reinterpret_cast<V2*>(us + i));
+            __builtin_nontemporal_store(V2{fa_p, fb_p}, reinterpret_cast<V2*>(ps + i));
+        } else {
+            if (st_a) { st_stream(us + i, fa_u); st_stream(ps + i, fa_p); }
+            if (st_b) { st_stream(us + i + 1, fb_u); st_stream(ps + i + 1, fb_p); }
+        }
+    }
+}
+#endif   // ARMON_GAD_X2
 
 template <int LIM, typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -174,19 +256,32 @@ k_acoustic_GAD_y(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us, T* __
     T us_m, ps_m, us_0, ps_0;
     phys::godunov(rho_m, rho_mm, c_m, c_mm, u_m, u_mm, p_m, p_mm, us_m, ps_m);
     phys::godunov(rho_i, rho_m, c_i, c_m, u_i, u_m, p_i, p_m, us_0, ps_0);
-    T rho_p = rho[i + s], c_p = c[i + s], u_p = u[i + s], p_p = p[i + s];               // row j0 + 1
+    // rows j + 1 .. j + kGadAhead are in flight while row j is computed: a row is requested kGadAhead steps before it is
+    // consumed (one step of 7 waves on a SIMD is shorter than a loaded HBM latency). No row above j1 is read.
+    T q[kGadAhead][4];
+#pragma unroll
+    for (int a = 0; a < kGadAhead; a++) {
+        const int64_t in = i + ((j0 + 1 + a < j1) ? (int64_t)(a + 1) : (j1 - j0)) * s;
+        q[a][0] = rho[in]; q[a][1] = c[in]; q[a][2] = u[in]; q[a][3] = p[in];
+    }
     for (int64_t j = j0; j < j1; j++, i += s) {
-        // row j + 2 is requested before row j + 1 is consumed (the loads of a step overlap the arithmetic of the previous one)
-        const int64_t in = (j + 1 < j1) ? i + 2 * s : i + s;
+        const int64_t in = i + ((j + 1 + kGadAhead < j1) ? (int64_t)(kGadAhead + 1) : (j1 - j)) * s;
         const T rho_n = rho[in], c_n = c[in], u_n = u[in], p_n = p[in];
+        const T rho_p = q[0][0], c_p = q[0][1], u_p = q[0][2], p_p = q[0][3];          // row j + 1
         T us_p, ps_p, a, b;
+#ifdef ARMON_GAD_NOCOMPUTE
+        us_p = rho_p + c_p; ps_p = u_p + p_p; a = us_m + rho_i + c_i; b = ps_m + u_i + p_i;
+#else
         phys::godunov(rho_p, rho_i, c_p, c_i, u_p, u_i, p_p, p_i, us_p, ps_p);         // interface j+1 | j, once
         phys::gad_flux<LIM>(dt, dx, rho_m, c_m, u_m, p_m, rho_i, c_i, u_i, p_i, us_m, ps_m, us_0, ps_0, us_p, ps_p, a, b);
+#endif
         st_stream(us + i, a);
         st_stream(ps + i, b);
         rho_m = rho_i; c_m = c_i; u_m = u_i; p_m = p_i;
         rho_i = rho_p; c_i = c_p; u_i = u_p; p_i = p_p;
-        rho_p = rho_n; c_p = c_n; u_p = u_n; p_p = p_n;
+#pragma unroll
+        for (int a2 = 0; a2 + 1 < kGadAhead; a2++) { q[a2][0] = q[a2 + 1][0]; q[a2][1] = q[a2 + 1][1]; q[a2][2] = q[a2 + 1][2]; q[a2][3] = q[a2 + 1][3]; }
+        q[kGadAhead - 1][0] = rho_n; q[kGadAhead - 1][1] = c_n; q[kGadAhead - 1][2] = u_n; q[kGadAhead - 1][3] = p_n;
         us_m = us_0; ps_m = ps_0;
         us_0 = us_p; ps_0 = ps_p;
     }
@@ -562,6 +657,20 @@ int acoustic_impl(armon_ctx* ctx, armon_range r, int64_t s, T* us, T* ps, const 
     return check_launch("acoustic");
 }
 
+#if ARMON_GAD_X2
+template <int LIM>
+void launch_gad_x2(dim3 grid, dim3 block, hipStream_t st, armon_range r, double dt, double dx, double* us, double* ps,
+                   const double* rho, const double* ua, const double* p, const double* c)
+{
+    hipLaunchKernelGGL((k_acoustic_GAD_x2<LIM>), grid, block, 0, st, r, dt, dx, us, ps, rho, ua, p, c);
+}
+template <int LIM>
+void launch_gad_x2(dim3, dim3, hipStream_t, armon_range, float, float, float*, float*, const float*, const float*, const float*,
+                   const float*)
+{
+}   // fp32 keeps the one-cell-per-lane form (form 3 is never chosen for it)
+#endif
+
 template <typename T>
 int acoustic_GAD_impl(armon_ctx* ctx, armon_range r, int64_t s, T dt, T dx, T* us, T* ps, const T* rho, const T* ua,
                       const T* p, const T* c, int limiter)
@@ -573,12 +682,28 @@ int acoustic_GAD_impl(armon_ctx* ctx, armon_range r, int64_t s, T dt, T dx, T* u
     range_grid(r, 1, grid, block);
     // form of the kernel: 1 = lanes along the sweep (s == 1), 2 = march along the sweep (s == row pitch), 0 = the
     // reference's own shape (any other stride)
-    const int form = (s == 1) ? 1 : ((s == r.col_step && r.col_len > 1) ? 2 : 0);
+    int form = (s == 1) ? 1 : ((s == r.col_step && r.col_len > 1) ? 2 : 0);
     if (form == 1) grid.x = (unsigned)(((r.row_len + kGadValid - 1) / kGadValid + kBlock / 64 - 1) / (kBlock / 64));   // waves of 62 fluxes
+#if ARMON_GAD_X2
+    if (form == 1 && sizeof(T) == 8 && r.col_step % 2 == 0 &&
+        ((uintptr_t)us | (uintptr_t)ps | (uintptr_t)rho | (uintptr_t)ua | (uintptr_t)p | (uintptr_t)c) % 16 == 0) {
+        form = 3;                                                    // strips of 120 fluxes, a workgroup = 4 rows of one strip
+        grid.x = (unsigned)((r.row_len + ((r.col_start + r.row_start) & 7) + kGadStride2 - 1) / kGadStride2);
+        const int64_t gy = (r.col_len + kBlock / 64 - 1) / (kBlock / 64);
+        grid.y = (unsigned)(gy < 65535 ? gy : 65535);
+    }
+#endif
     if (form == 2) grid.y = (unsigned)((r.col_len + kGadRows - 1) / kGadRows);
+#if ARMON_GAD_X2
+#define ARMON_GAD_X2_LAUNCH(LIM) launch_gad_x2<LIM>(grid, block, ctx->stream, r, dt, dx, us, ps, rho, ua, p, c)
+#else
+#define ARMON_GAD_X2_LAUNCH(LIM) (void)0
+#endif
 #define ARMON_GAD_LAUNCH(LIM)                                                                                              \
     do {                                                                                                                   \
-        if (form == 1)                                                                                                     \
+        if (form == 3)                                                                                                     \
+            ARMON_GAD_X2_LAUNCH(LIM);                                                                                      \
+        else if (form == 1)                                                                                                \
             hipLaunchKernelGGL((k_acoustic_GAD_x<LIM, T>), grid, block, 0, ctx->stream, r, dt, dx, us, ps, rho, ua, p, c);  \
         else if (form == 2)                                                                                                \
             hipLaunchKernelGGL((k_acoustic_GAD_y<LIM, T>), grid, block, 0, ctx->stream, r, s, dt, dx, us, ps, rho, ua, p, c); \

@@ -159,6 +159,37 @@ def test_acoustic_GAD(dev, L, oracle, shape, axis, limiter):
     assert_same(d, f, ("us", "ps"))
 
 
+@pytest.mark.parametrize("limiter", [0, 1])
+@pytest.mark.parametrize("shift", range(8))
+@pytest.mark.parametrize("shape", [(250, 9), (1006, 5), (121, 6)])
+def test_acoustic_GAD_x_strips(dev, L, oracle, shape, shift, limiter):
+    """The two-cells-per-lane x form (even row pitch, fp64): several strips of 120 fluxes per row, rows that are not a
+    multiple of the 4 of a workgroup, every position of the first flux within its 64-B sector, short last strips."""
+    nx, ny = shape
+    f = rand_state(nx, ny, 40 + shift)
+    d = upload(dev, f)
+    r = oracle.domain_range(nx, ny, G, (-2 + shift, 0), (3 - (shift % 3), 0))
+    dt, dx = 1e-3, 1.0 / nx
+    oracle.lib().armon_oracle_acoustic_GAD(r, 1, dt, dx, *(oracle.ptr(f[k]) for k in ("us", "ps", "rho", "u", "p", "c")), limiter)
+    assert L.armon_hip_acoustic_GAD(dev.ctx, conv(r), 1, dt, dx, *(P(d, k) for k in ("us", "ps", "rho", "u", "p", "c")), limiter) == 0
+    assert_same(d, f, ("us", "ps"))
+
+
+def test_acoustic_GAD_x_unaligned_arrays(dev, L, oracle):
+    """Arrays that do not start on 16 bytes (a view one cell into an allocation) take the one-cell-per-lane form: same bits."""
+    nx, ny = 250, 9
+    n = (nx + 2 * G) * (ny + 2 * G)
+    f = rand_state(nx, ny, 51)
+    r = oracle.domain_range(nx, ny, G, (-2, 0), (3, 0))
+    dt, dx = 1e-3, 1.0 / nx
+    big = {k: dev.from_host(np.concatenate([[0.0], f[k]])) for k in ("us", "ps", "rho", "u", "p", "c")}
+    oracle.lib().armon_oracle_acoustic_GAD(r, 1, dt, dx, *(oracle.ptr(f[k]) for k in ("us", "ps", "rho", "u", "p", "c")), 1)
+    assert L.armon_hip_acoustic_GAD(dev.ctx, conv(r), 1, dt, dx,
+                                    *(C.c_void_p(big[k].ptr + 8) for k in ("us", "ps", "rho", "u", "p", "c")), 1) == 0
+    for k in ("us", "ps"):
+        assert np.array_equal(big[k].to_host()[1:], f[k])
+
+
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_cell_update(dev, L, oracle, shape, axis):
