@@ -94,7 +94,7 @@ int armon_hip_init(int device_id, void* stream, armon_ctx** out)
     }
     int rc = ensure_partials(ctx, 8192);
     if (rc != ARMON_OK) { armon_hip_destroy(ctx); return rc; }
-    for (const char* knob : {"ARMON_XS_NITER", "ARMON_Y_SEG", "ARMON_SWEEP_ALIGN", "ARMON_Y_COLS1", "ARMON_X_XCD", "ARMON_X_ROWS"}) {
+    for (const char* knob : {"ARMON_XS_NITER", "ARMON_Y_SEG", "ARMON_SWEEP_ALIGN", "ARMON_Y_COLS1", "ARMON_X_XCD", "ARMON_X_ROWS", "ARMON_Y_SX"}) {
         const char* v = getenv(knob);
         if (v && *v) (void)armon_hip_set_tuning(ctx, knob, atoi(v));
     }
@@ -111,6 +111,7 @@ int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value)
     else if (!strcmp(knob, "ARMON_Y_COLS1")) ctx->tune_y_cols1 = value > 0;
     else if (!strcmp(knob, "ARMON_X_XCD")) ctx->tune_x_xcd = value > 0;
     else if (!strcmp(knob, "ARMON_X_ROWS")) ctx->tune_x_rows = (value == 1 || value == 2) ? value : 0;
+    else if (!strcmp(knob, "ARMON_Y_SX")) ctx->tune_y_sx = (value == 1 || value == 2) ? value : 0;
     else ARMON_REQUIRE(false, "unknown tuning knob '%s'", knob);
     return ARMON_OK;
 }

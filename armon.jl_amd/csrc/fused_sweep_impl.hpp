@@ -79,6 +79,8 @@ struct sweep_args {
     int32_t xshift;                // Y sweep: columns the block origin is moved left (line-aligned row segments)
     int32_t xcd_remap;             // X sweep: XCD-aware workgroup placement (ARMON_X_XCD)
     int32_t x_wg_along_x = 0;      // X sweep: a workgroup = kXSRows consecutive strips of one row (else: one strip of kXSRows rows)
+    int32_t x_row_align = 0;       // X sweep: strip origins aligned row by row (row pitch not a multiple of a 64-B sector)
+    int32_t y_sx = 0;              // Y sweep: rows are stored in sector-aligned windows handed over through LDS (see k_sweep_y)
     armon_dt_state* st = nullptr;   // device-resident time step (graph replay): dt is then a factor of st->current_dt
     real dt, dx, gamma;
     real fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
@@ -318,6 +320,20 @@ k_sweep_y(sweep_args a)
     unsigned lo_off = 0;
     unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;     // row j - LAG relative to row o0 (wraps until valid)
 
+    // Store exchange (a.y_sx; rows that do not all start on 64-B sectors, i.e. a pitch that is not a multiple of a sector).
+    // A lane's column is fixed for the whole march, so on such rows every wave's 512-B store would begin and end inside a
+    // sector, and it is the partial-sector STORES that cost (tools/probes/probe_ypitch.hip: misplaced loads +0.6 %, stores
+    // +11 % at half a sector, +21 % on odd pitches). The workgroup's row is therefore passed through LDS: thread t stores
+    // column (t - r) mod kYBlock of the workgroup, r = the row's phase in cells, so that all but the workgroup's two end
+    // pieces are whole sectors; one barrier per row, two LDS buffers.
+    __shared__ real sx_lds[2][4][kYBlock];
+    static_assert((kYBlock & (kYBlock - 1)) == 0, "the store exchange wraps columns with a mask");
+    constexpr int kSec = 64 / (int)sizeof(real);             // cells per sector
+    const int c0 = (int)(blockIdx.x * kYBlock) - a.xshift;   // first column of the workgroup
+    int sx_r = (int)(((int64_t)(jb - LAG + g) * a.row_len + g + c0) & (kSec - 1));    // phase of row j - LAG, j = jb
+    const int sx_dr = (int)(a.row_len & (kSec - 1));
+    int sx_buf = 0;
+
     // The state of row lj is loaded straight into the pipeline's cell ring, slot lj mod 8, PF steps before
     // the march reaches it. CHECKED steps handle everything (mirrored / clamped loads, masked stores,
     // p/c output); the steady state of a run uses the unchecked form: plain loads, unconditional stores.
@@ -371,7 +387,24 @@ k_sweep_y(sweep_args a)
             }
         }
         if (!CHECKED || (o >= o0 && o < o1)) {
-            if (active) {
+            if (a.y_sx) {                                    // uniform
+                real(*L)[kYBlock] = sx_lds[sx_buf];
+                L[0][threadIdx.x] = out.rho;
+                L[1][threadIdx.x] = out.ua;
+                L[2][threadIdx.x] = out.ut;
+                L[3][threadIdx.x] = out.E;
+                __syncthreads();
+                const int ci = ((int)threadIdx.x - sx_r) & (kYBlock - 1);
+                const int cx = c0 + ci;
+                if (cx >= 0 && cx < nx) {
+                    const unsigned cb = (unsigned)(cx + g) * (unsigned)sizeof(real);
+                    buf_store(w_rho, cb, so_off, L[0][ci]);
+                    buf_store(w_ua, cb, so_off, L[1][ci]);
+                    buf_store(w_ut, cb, so_off, L[2][ci]);
+                    buf_store(w_E, cb, so_off, L[3][ci]);
+                }
+                sx_buf ^= 1;
+            } else if (active) {
                 buf_store(w_rho, colb, so_off, out.rho);
                 buf_store(w_ua, colb, so_off, out.ua);
                 buf_store(w_ut, colb, so_off, out.ut);
@@ -380,6 +413,7 @@ k_sweep_y(sweep_args a)
             if (TRACK) cfl.add(out.ut, out.ua, c_lag);      // Y sweep: ut = u, ua = v
         }
         so_off += pitchb;
+        sx_r = (sx_r + sx_dr) & (kSec - 1);
     };
     auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 8
         for (int t = t0; t < t1; t += 8)
@@ -396,7 +430,8 @@ k_sweep_y(sweep_args a)
 
     // The block origin shift leaves the last workgroup of a row mostly past the last column: a wave with no
     // column at all skips the march (it still joins the block reduction below with neutral values).
-    const bool wave_idle = (int)(blockIdx.x * kYBlock + (threadIdx.x & ~63u)) - a.xshift >= nx;   // wave-uniform
+    // (not with the store exchange: every wave of the workgroup takes part in its barriers)
+    const bool wave_idle = !a.y_sx && (int)(blockIdx.x * kYBlock + (threadIdx.x & ~63u)) - a.xshift >= nx;   // wave-uniform
     if (!wave_idle) {
         static_for(std::make_integer_sequence<int, PF>{}, [&](auto k) { load(k, std::true_type{}); });
         run(std::true_type{}, 0, P < T8 ? P : T8);
@@ -446,6 +481,14 @@ k_sweep_y2(sweep_args a)
     int lj = jb;                     // next row to load and its offset from the run's first row
     unsigned lo_off = 0;
     unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;     // row j - LAG relative to row o0 (wraps until valid)
+
+    // store exchange as in k_sweep_y, in units of a lane's column PAIR (8 B; eight pairs per sector)
+    __shared__ float2 sx_lds[2][4][kYBlock];
+    static_assert((kYBlock & (kYBlock - 1)) == 0, "the store exchange wraps columns with a mask");
+    const int c0 = (int)(blockIdx.x * kYBlock) * 2 - a.xshift;     // first column of the workgroup (even)
+    int sx_r = (int)((((int64_t)(jb - LAG + g) * a.row_len + g + c0) >> 1) & 7);
+    const int sx_dr = (int)((a.row_len >> 1) & 7);
+    int sx_buf = 0;
 
     // The state of row lj is loaded straight into the pipeline's cell ring, slot lj mod 8, PF steps before
     // the march reaches it. CHECKED steps handle everything (mirrored / clamped loads, masked stores,
@@ -504,7 +547,25 @@ k_sweep_y2(sweep_args a)
             }
         }
         if (!CHECKED || (o >= o0 && o < o1)) {
-            if (active) {
+            if (a.y_sx) {                                    // uniform
+                float2(*L)[kYBlock] = sx_lds[sx_buf];
+                L[0][threadIdx.x] = float2{out.rho.x, out.rho.y};
+                L[1][threadIdx.x] = float2{out.ua.x, out.ua.y};
+                L[2][threadIdx.x] = float2{out.ut.x, out.ut.y};
+                L[3][threadIdx.x] = float2{out.E.x, out.E.y};
+                __syncthreads();
+                const int ci = ((int)threadIdx.x - sx_r) & (kYBlock - 1);
+                const int cx = c0 + 2 * ci;
+                if (cx >= 0 && cx < nx) {
+                    const unsigned cb = (unsigned)(cx + g) * (unsigned)sizeof(real);
+                    const float2 q0 = L[0][ci], q1 = L[1][ci], q2 = L[2][ci], q3 = L[3][ci];
+                    buf_store2(w_rho, cb, so_off, q0.x, q0.y);
+                    buf_store2(w_ua, cb, so_off, q1.x, q1.y);
+                    buf_store2(w_ut, cb, so_off, q2.x, q2.y);
+                    buf_store2(w_E, cb, so_off, q3.x, q3.y);
+                }
+                sx_buf ^= 1;
+            } else if (active) {
                 buf_store2(w_rho, colb, so_off, out.rho.x, out.rho.y);
                 buf_store2(w_ua, colb, so_off, out.ua.x, out.ua.y);
                 buf_store2(w_ut, colb, so_off, out.ut.x, out.ut.y);
@@ -516,6 +577,7 @@ k_sweep_y2(sweep_args a)
             }
         }
         so_off += pitchb;
+        sx_r = (sx_r + sx_dr) & 7;
     };
     auto run = [&](auto checked, int t0, int t1) {           // steps [t0, t1), both multiples of 8
         for (int t = t0; t < t1; t += 8)
@@ -600,13 +662,22 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     real* out[4] = {a.rho_out + row_off, a.ua_out + row_off, a.ut_out + row_off, a.E_out + row_off};
     // 16-B accesses need every lane pair on an even cell of an even-pitched row; strip origins are multiples of 8 cells
     // from the row start (x_first), so an odd o_lo (partial sweeps with LAG = 3) only masks half of one pair
-    const bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && ((a.x_first + a.g) % 2 == 0);   // uniform
+    bool vec_ok = (K == 2) && (a.row_len % 2 == 0) && ((a.x_first + a.g) % 2 == 0);         // uniform
+    // When the row pitch is not a multiple of a sector (8 doubles, 16 floats) the rows start at different places of their 64-B sectors and no single
+    // origin aligns them all (fp64 at 16388 cells per row: X 1.05x the copy, profiles/r03_row_pitch.txt): the origin is then
+    // taken row by row, less than a sector below o_lo, where that row's stores start on a sector (arrays start on one). Every
+    // lane pair then sits on 16 B (fp32: 8 B) whatever the parity of the pitch.
+    int64_t x_first = a.x_first;
+    if (ROW == 0 && a.x_row_align) {
+        x_first = a.o_lo - ((row_off + a.o_lo) & (64 / (int)sizeof(real) - 1));
+        vec_ok = (K == 2);
+    }
 
     SW sw{a.dt, a.dx, a.gamma};
     cfl_track cfl;
     // Strip origins are aligned so that a strip's stores start on a 64-B sector of the ghosted row (for the
     // usual STRIDE = 120 = 15 sectors); the first strip of a row is then a short one (stores masked below o_lo).
-    const int64_t w_first = a.x_first + strip0 * STRIDE;
+    const int64_t w_first = x_first + strip0 * STRIDE;
     // Strips are real-buffered in registers: the loads of strip it+1 are issued before strip it is
     // computed (the loop is unrolled by the two buffers, so no loaded register is ever copied).
     St buf[2][4];
@@ -1149,9 +1220,10 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     }
     const int halo = k1 ? PIPE::LAG : 4;
     const int64_t per_block = (int64_t)niter * (64 * (k1 ? 1 : 2) - 2 * halo);
-    dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
+    const int64_t x_lowest = a.x_row_align ? a.o_lo - (64 / (int64_t)sizeof(real) - 1) : a.x_first;   // strips are counted from the lowest origin of any row
+    dim3 grid((unsigned)((a.o_hi - x_lowest + per_block - 1) / per_block), (unsigned)((a.ny + kXSRows - 1) / kXSRows));
     if (a.x_wg_along_x && !k1 && niter == 1)                  // kXSRows strips of one row per workgroup
-        grid = dim3((unsigned)((a.o_hi - a.x_first + kXSRows * per_block - 1) / (kXSRows * per_block)), (unsigned)a.ny);
+        grid = dim3((unsigned)((a.o_hi - x_lowest + kXSRows * per_block - 1) / (kXSRows * per_block)), (unsigned)a.ny);
     *n_blocks = (int64_t)grid.x * grid.y * kXSRows;          // one pair of maxima per wave
 #if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
     if (k1)
@@ -1346,6 +1418,23 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.xshift = (X || !align) ? 0 : d->nghost % 16;
     a.x_first = X ? (align ? a.o_lo - (a.o_lo + d->nghost) % 8 : a.o_lo) : 0;
     a.xcd_remap = ctx->tune_x_xcd;
+    // the Y march stores through LDS when its rows do not all start on sectors (ARMON_Y_SX: 1 always, 2 never)
+    a.y_sx = 0;
+    if (!X && align && ctx->tune_y_sx != 2) {
+        const uintptr_t outs = (uintptr_t)d->rho_out | (uintptr_t)d->u_out | (uintptr_t)d->v_out | (uintptr_t)d->E_out;
+        a.y_sx = outs % 64 == 0 && ((a.row_len * (int64_t)sizeof(real)) % 64 != 0 || ctx->tune_y_sx == 1);
+    }
+    // origins row by row when one origin cannot align every row (the one-strip-per-wave form only; the A/B forms keep one)
+    a.x_row_align = 0;
+#ifndef ARMON_XS_MULTI
+    {
+        const uintptr_t bases = (uintptr_t)d->rho_in | (uintptr_t)d->u_in | (uintptr_t)d->v_in | (uintptr_t)d->E_in |
+                                (uintptr_t)d->rho_out | (uintptr_t)d->u_out | (uintptr_t)d->v_out | (uintptr_t)d->E_out |
+                                (uintptr_t)d->p_out | (uintptr_t)d->c_out;
+        a.x_row_align = X && align && d->x_kernel == 0 && ctx->tune_xs_niter <= 1 && a.row_len % (64 / (int64_t)sizeof(real)) != 0 &&
+                        bases % 64 == 0;
+    }
+#endif
     // workgroup shape of the X sweep (profiles/r03_ab_x_workgroup_shape.txt): 4 consecutive strips of one row pay for fp32
     // (1.54 -> 1.43 ms at 16384²: a 512-B strip shares a quarter of its 128-B lines with its neighbours) and not for fp64
     // (equal at 16384² and 4096 x 8192, +3 % at 8192²), which keeps one strip of 4 rows. ARMON_X_ROWS: 1 / 2 force a shape.

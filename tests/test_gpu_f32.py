@@ -140,3 +140,22 @@ def test_f32_x_sweep_workgroup_shapes_give_the_same_bits(monkeypatch, test, N, o
         assert s1.cycles == s0.cycles and s1.last_dt == s0.last_dt
         for k in ("rho", "u", "v", "E", "p"):       # real cells: the ghost rows of a ping-pong partner are never written
             assert np.array_equal(s1.data.real_view(h1[k]), s0.data.real_view(h0[k])), (shape, k)
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+@pytest.mark.parametrize("test,N,opts", [("Sod_circ", (520, 300), {}),                  # pitch 528 floats: rows on sectors
+                                         ("Sod_circ", (512, 300), {}),                  # 520: every other row mid-sector (two columns per lane)
+                                         ("Sod_circ", (1030, 130), dict(nghost=6)),     # 1042: 8-B steps, several workgroups per row
+                                         ("Sedov", (515, 263), dict(nghost=5)),         # odd pitch: one column per lane
+                                         ("Bizarrium", (40, 600), dict(axis_splitting="Y_only"))])
+def test_f32_y_march_store_exchange_gives_the_same_bits(monkeypatch, test, N, opts, exact):
+    """fp32 Y marches (one and two columns per lane) with the LDS store exchange forced on / off / automatic."""
+    o = dict(N=N, maxcycle=7, use_fused_sweep=True, exact_arithmetic=exact, **opts)
+    monkeypatch.setenv("ARMON_Y_SX", "2")
+    _p, s0, h0 = run32(test, **o)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ARMON_Y_SX", mode)
+        _p, s1, h1 = run32(test, **o)
+        assert s1.cycles == s0.cycles and s1.last_dt == s0.last_dt
+        for k in ("rho", "u", "v", "E", "p"):
+            assert np.array_equal(s1.data.real_view(h1[k]), s0.data.real_view(h0[k])), (mode, k)

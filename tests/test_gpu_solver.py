@@ -77,6 +77,8 @@ def test_reference_golden_unasserted_cases(test, fused):
     ("Sedov", (300, 301), dict(nghost=7, maxcycle=8)),
     ("Sod_circ", (770, 515), dict(axis_splitting="Godunov", maxcycle=7)),      # X-last cycles: X sweep dt tracking
     ("Bizarrium", (513, 129), dict(axis_splitting="X_only", maxcycle=8)),
+    # row pitch 4 past a multiple of 8 cells: every other row starts mid-sector (X strip origins taken row by row)
+    ("Sod_circ", (1004, 37), dict(maxcycle=8)),
 ])
 def test_bit_exact_against_oracle(oracle, test, N, opts, fused):
     """Whole-solver parity: every real cell of ρ,u,v,E,p, the cycle count and dt are identical."""
@@ -367,7 +369,8 @@ def test_tune_placement_keeps_the_state(oracle):
 
 @pytest.mark.parametrize("knobs", [dict(ARMON_SWEEP_ALIGN="0"), dict(ARMON_XS_NITER="1"), dict(ARMON_XS_NITER="3"),
                                    dict(ARMON_XS_NITER="137"), dict(ARMON_Y_SEG="16"), dict(ARMON_Y_SEG="1000"), dict(ARMON_X_XCD="1"),
-                                   dict(ARMON_X_XCD="0"), dict(ARMON_X_ROWS="1"), dict(ARMON_X_ROWS="2")],
+                                   dict(ARMON_X_XCD="0"), dict(ARMON_X_ROWS="1"), dict(ARMON_X_ROWS="2"),
+                                   dict(ARMON_Y_SX="1"), dict(ARMON_Y_SX="2")],
                          ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
 @pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
 def test_tuning_knobs_do_not_change_results(monkeypatch, knobs, exact):
@@ -385,6 +388,26 @@ def test_tuning_knobs_do_not_change_results(monkeypatch, knobs, exact):
     assert stats.cycles == ref_stats.cycles and stats.last_dt == ref_stats.last_dt
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(stats.data.real_view(host[k]), ref_stats.data.real_view(ref[k])), k
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "tuned"])
+@pytest.mark.parametrize("test,N,opts", [("Sod_circ", (328, 300), {}),                          # pitch 336: every row on a sector
+                                         ("Sod_circ", (332, 300), {}),                          # 340: every other row mid-sector
+                                         ("Sedov", (515, 263), dict(nghost=5)),                 # odd pitch, several workgroups per row
+                                         ("Sod_circ", (700, 40), dict(axis_splitting="Godunov")),
+                                         ("Bizarrium", (40, 600), dict(axis_splitting="Y_only"))])
+def test_y_march_store_exchange_gives_the_same_bits(monkeypatch, test, N, opts, exact):
+    """The Y march hands its rows over through LDS and stores sector-aligned windows when the pitch is not a multiple of a
+    sector (ARMON_Y_SX=0, automatic), always (1) or never (2): who STORES a cell must not change it."""
+    o = dict(N=N, maxcycle=7, exact_arithmetic=exact, **opts)
+    monkeypatch.setenv("ARMON_Y_SX", "2")
+    _p, s0, h0 = run(test, **o)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ARMON_Y_SX", mode)
+        _p, s1, h1 = run(test, **o)
+        assert s1.cycles == s0.cycles and s1.last_dt == s0.last_dt
+        for k in ("rho", "u", "v", "E", "p"):
+            assert np.array_equal(s1.data.real_view(h1[k]), s0.data.real_view(h0[k])), (mode, k)
 
 
 @pytest.mark.parametrize("test,N", [("Sod_circ", (300, 200)), ("Sod_circ", (57, 61)), ("Sedov", (123, 77)), ("Sod", (8, 500)),
