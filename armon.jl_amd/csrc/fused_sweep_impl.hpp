@@ -278,6 +278,7 @@ int fold_dt_launch(armon_ctx* ctx, real* partials, int64_t n, real dx, real dy, 
 #define ARMON_Y_BLOCK 256        // columns (= lanes) per workgroup of the Y march (tuning macro)
 #endif
 constexpr int kYBlock = ARMON_Y_BLOCK;
+constexpr int kYSxBlock = 512;     // lanes per workgroup of the Y march with the LDS store exchange (sweep_args::y_sx)
 #ifndef ARMON_Y_PF
 #define ARMON_Y_PF 4             // rows prefetched ahead of the march (≤ 5: the cell ring has 8 slots)
 #endif
@@ -285,8 +286,8 @@ constexpr int kYBlock = ARMON_Y_BLOCK;
 #define ARMON_Y_WAVES 2          // minimum waves per SIMD the Y march is compiled for (register budget)
 #endif
 
-template <class PIPE, bool TRACK>
-__global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
+template <class PIPE, bool TRACK, int BLOCK = kYBlock, bool SX = false>
+__global__ void __launch_bounds__(BLOCK, ARMON_Y_WAVES)
 k_sweep_y(sweep_args a)
 {
     if (!sweep_begin(a)) return;
@@ -295,7 +296,7 @@ k_sweep_y(sweep_args a)
     const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
     // The block origin is shifted left by a.xshift columns so that a wave's 512-B row segment starts on a
     // 64-B sector / 128-B line of the ghosted row instead of g cells into one (probe_access: -9 % time).
-    const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x) - a.xshift;
+    const int xr = (int)(blockIdx.x * BLOCK + threadIdx.x) - a.xshift;
     const bool active = xr >= 0 && xr < nx;
     const int x = active ? xr : (xr < 0 ? 0 : nx - 1);   // idle lanes shadow an edge column and never store
     const int o_hi = (int)a.o_hi;
@@ -320,16 +321,18 @@ k_sweep_y(sweep_args a)
     unsigned lo_off = 0;
     unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;     // row j - LAG relative to row o0 (wraps until valid)
 
-    // Store exchange (a.y_sx; rows that do not all start on 64-B sectors, i.e. a pitch that is not a multiple of a sector).
+    // Store exchange (SX, chosen by sweep_args::y_sx; rows that do not all start on 64-B sectors, i.e. a pitch that is not a multiple of a sector).
     // A lane's column is fixed for the whole march, so on such rows every wave's 512-B store would begin and end inside a
     // sector, and it is the partial-sector STORES that cost (tools/probes/probe_ypitch.hip: misplaced loads +0.6 %, stores
     // +11 % at half a sector, +21 % on odd pitches). The workgroup's row is therefore passed through LDS: thread t stores
-    // column (t - r) mod kYBlock of the workgroup, r = the row's phase in cells, so that all but the workgroup's two end
-    // pieces are whole sectors; one barrier per row, two LDS buffers.
-    __shared__ real sx_lds[2][4][kYBlock];
-    static_assert((kYBlock & (kYBlock - 1)) == 0, "the store exchange wraps columns with a mask");
+    // column (t - r) mod BLOCK of the workgroup, r = the row's phase in cells, so that all but the workgroup's two end
+    // pieces are whole sectors; one barrier per row, two LDS buffers. The kernel is instantiated for it with workgroups of
+    // kYSxBlock = 512 lanes (half as many end pieces: fp32 bench shape 1.55 -> 1.50 ms; without the exchange 256 lanes are
+    // faster, profiles/r03_row_pitch_repairs.txt) and without any of this code for the usual, sector-aligned pitches.
+    __shared__ real sx_lds[SX ? 2 : 1][SX ? 4 : 1][SX ? BLOCK : 1];
+    static_assert((BLOCK & (BLOCK - 1)) == 0, "the store exchange wraps columns with a mask");
     constexpr int kSec = 64 / (int)sizeof(real);             // cells per sector
-    const int c0 = (int)(blockIdx.x * kYBlock) - a.xshift;   // first column of the workgroup
+    const int c0 = (int)(blockIdx.x * BLOCK) - a.xshift;   // first column of the workgroup
     int sx_r = (int)(((int64_t)(jb - LAG + g) * a.row_len + g + c0) & (kSec - 1));    // phase of row j - LAG, j = jb
     const int sx_dr = (int)(a.row_len & (kSec - 1));
     int sx_buf = 0;
@@ -387,14 +390,14 @@ k_sweep_y(sweep_args a)
             }
         }
         if (!CHECKED || (o >= o0 && o < o1)) {
-            if (a.y_sx) {                                    // uniform
-                real(*L)[kYBlock] = sx_lds[sx_buf];
+            if constexpr (SX) {
+                auto& L = sx_lds[sx_buf];
                 L[0][threadIdx.x] = out.rho;
                 L[1][threadIdx.x] = out.ua;
                 L[2][threadIdx.x] = out.ut;
                 L[3][threadIdx.x] = out.E;
                 __syncthreads();
-                const int ci = ((int)threadIdx.x - sx_r) & (kYBlock - 1);
+                const int ci = ((int)threadIdx.x - sx_r) & (BLOCK - 1);
                 const int cx = c0 + ci;
                 if (cx >= 0 && cx < nx) {
                     const unsigned cb = (unsigned)(cx + g) * (unsigned)sizeof(real);
@@ -431,7 +434,7 @@ k_sweep_y(sweep_args a)
     // The block origin shift leaves the last workgroup of a row mostly past the last column: a wave with no
     // column at all skips the march (it still joins the block reduction below with neutral values).
     // (not with the store exchange: every wave of the workgroup takes part in its barriers)
-    const bool wave_idle = !a.y_sx && (int)(blockIdx.x * kYBlock + (threadIdx.x & ~63u)) - a.xshift >= nx;   // wave-uniform
+    const bool wave_idle = !SX && (int)(blockIdx.x * BLOCK + (threadIdx.x & ~63u)) - a.xshift >= nx;   // wave-uniform
     if (!wave_idle) {
         static_for(std::make_integer_sequence<int, PF>{}, [&](auto k) { load(k, std::true_type{}); });
         run(std::true_type{}, 0, P < T8 ? P : T8);
@@ -439,14 +442,14 @@ k_sweep_y(sweep_args a)
         run(std::true_type{}, M, T8);
     }
 
-    if (TRACK) cfl_block_store<kYBlock / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
+    if (TRACK) cfl_block_store<BLOCK / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
 
 // Two columns per lane: the fp32 form of the Y march. With 4-B elements one column per lane moves only 256 B per
 // wave and instruction; two adjacent columns per lane (8-B accesses, two independent pipelines = twice the ILP at
 // the register cost of one fp64 pipeline) restore the 512-B row segments of the fp64 kernel.
-template <class PIPE, bool TRACK>
-__global__ void __launch_bounds__(kYBlock, ARMON_Y_WAVES)
+template <class PIPE, bool TRACK, int BLOCK = kYBlock, bool SX = false>
+__global__ void __launch_bounds__(BLOCK, ARMON_Y_WAVES)
 k_sweep_y2(sweep_args a)
 {
     if (!sweep_begin(a)) return;
@@ -454,7 +457,7 @@ k_sweep_y2(sweep_args a)
     constexpr int PF = ARMON_Y_PF;   // rows in flight per lane, ahead of the march
     const int nx = (int)a.nx, ny = (int)a.ny, g = a.g;
     // Two adjacent columns per lane (nx, g and a.xshift are even here): xr, xr + 1; 8-B accesses.
-    const int xr = (int)(blockIdx.x * kYBlock + threadIdx.x) * 2 - a.xshift;
+    const int xr = (int)(blockIdx.x * BLOCK + threadIdx.x) * 2 - a.xshift;
     const bool active = xr >= 0 && xr < nx;
     const int x = active ? xr : (xr < 0 ? 0 : nx - 2);   // idle lanes shadow an edge pair and never store
     const int o_hi = (int)a.o_hi;
@@ -483,9 +486,9 @@ k_sweep_y2(sweep_args a)
     unsigned so_off = (unsigned)(jb - LAG - o0) * pitchb;     // row j - LAG relative to row o0 (wraps until valid)
 
     // store exchange as in k_sweep_y, in units of a lane's column PAIR (8 B; eight pairs per sector)
-    __shared__ float2 sx_lds[2][4][kYBlock];
-    static_assert((kYBlock & (kYBlock - 1)) == 0, "the store exchange wraps columns with a mask");
-    const int c0 = (int)(blockIdx.x * kYBlock) * 2 - a.xshift;     // first column of the workgroup (even)
+    __shared__ float2 sx_lds[SX ? 2 : 1][SX ? 4 : 1][SX ? BLOCK : 1];
+    static_assert((BLOCK & (BLOCK - 1)) == 0, "the store exchange wraps columns with a mask");
+    const int c0 = (int)(blockIdx.x * BLOCK) * 2 - a.xshift;     // first column of the workgroup (even)
     int sx_r = (int)((((int64_t)(jb - LAG + g) * a.row_len + g + c0) >> 1) & 7);
     const int sx_dr = (int)((a.row_len >> 1) & 7);
     int sx_buf = 0;
@@ -547,14 +550,14 @@ k_sweep_y2(sweep_args a)
             }
         }
         if (!CHECKED || (o >= o0 && o < o1)) {
-            if (a.y_sx) {                                    // uniform
-                float2(*L)[kYBlock] = sx_lds[sx_buf];
+            if constexpr (SX) {
+                auto& L = sx_lds[sx_buf];
                 L[0][threadIdx.x] = float2{out.rho.x, out.rho.y};
                 L[1][threadIdx.x] = float2{out.ua.x, out.ua.y};
                 L[2][threadIdx.x] = float2{out.ut.x, out.ut.y};
                 L[3][threadIdx.x] = float2{out.E.x, out.E.y};
                 __syncthreads();
-                const int ci = ((int)threadIdx.x - sx_r) & (kYBlock - 1);
+                const int ci = ((int)threadIdx.x - sx_r) & (BLOCK - 1);
                 const int cx = c0 + 2 * ci;
                 if (cx >= 0 && cx < nx) {
                     const unsigned cb = (unsigned)(cx + g) * (unsigned)sizeof(real);
@@ -597,7 +600,7 @@ k_sweep_y2(sweep_args a)
     run(std::false_type{}, P, M);
     run(std::true_type{}, M, T8);
 
-    if (TRACK) cfl_block_store<kYBlock / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
+    if (TRACK) cfl_block_store<BLOCK / 64>(cfl, a.partials, (int64_t)blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
 }
 
 // ---- X sweep, spatial form (lanes along x, DPP neighbour exchange) -------------------------------------
@@ -1180,16 +1183,27 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         // fp32, tuned arithmetic: two columns per lane when every row is 8-B aligned (even pitch and ghost width).
         // (Not instantiated for the exact flavour: build time; the tests require it to equal the one-column kernel.)
         if (axis == ARMON_AXIS_Y && a.nx % 2 == 0 && a.g % 2 == 0 && a.nx >= 2 && !ctx->tune_y_cols1) {
-            dim3 grid((unsigned)((a.nx + a.xshift + 2 * kYBlock - 1) / (2 * kYBlock)), (unsigned)((n_out + a.seg - 1) / a.seg));
+            const int block = a.y_sx ? kYSxBlock : kYBlock;
+            dim3 grid((unsigned)((a.nx + a.xshift + 2 * block - 1) / (2 * block)), (unsigned)((n_out + a.seg - 1) / a.seg));
             *n_blocks = (int64_t)grid.x * grid.y;
-            hipLaunchKernelGGL((k_sweep_y2<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
+            if (a.y_sx)
+                hipLaunchKernelGGL((k_sweep_y2<PIPE, TRACK, kYSxBlock, true>), grid, dim3(block), 0, ctx->stream, a);
+            else
+                hipLaunchKernelGGL((k_sweep_y2<PIPE, TRACK>), grid, dim3(block), 0, ctx->stream, a);
             return check_launch("sweep_y2");
         }
     }
     if (axis == ARMON_AXIS_Y) {
-        dim3 grid((unsigned)((a.nx + a.xshift + kYBlock - 1) / kYBlock), (unsigned)((n_out + a.seg - 1) / a.seg));
+        const int block = a.y_sx ? kYSxBlock : kYBlock;
+        dim3 grid((unsigned)((a.nx + a.xshift + block - 1) / block), (unsigned)((n_out + a.seg - 1) / a.seg));
         *n_blocks = (int64_t)grid.x * grid.y;
-        hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK>), grid, dim3(kYBlock), 0, ctx->stream, a);
+        if constexpr (!PIPE::kExact) {                       // (y_sx is never set for the exact flavour: library size)
+            if (a.y_sx) {
+                hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK, kYSxBlock, true>), grid, dim3(block), 0, ctx->stream, a);
+                return check_launch("sweep_y (store exchange)");
+            }
+        }
+        hipLaunchKernelGGL((k_sweep_y<PIPE, TRACK>), grid, dim3(block), 0, ctx->stream, a);
         return check_launch("sweep_y");
     }
 #if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
@@ -1252,10 +1266,10 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
 // of long-lived workgroups exposes the whole ramp-up and tail: 4096², 137 rows in one round is 5 % slower than 32
 // rows in 4.25). Measured at 16384² (tools/y_ab_r02.sh, one process): 128 rows 3.17 ms, 256: 3.12, 421: 3.09,
 // 529: 3.08, 713: 3.09, 1093: 3.12, 2341 (one round, 11 % of the slots empty): 3.19.
-int y_run_length(int n_cu, int64_t nx, int64_t ny, int lag, int cols_per_lane)
+int y_run_length(int n_cu, int64_t nx, int64_t ny, int lag, int cols_per_lane, int block)
 {
-    const double slots = (double)n_cu * ARMON_Y_WAVES * 4 / (kYBlock / 64);         // workgroups resident at once
-    const int64_t cols = (nx + 16 + (int64_t)kYBlock * cols_per_lane - 1) / ((int64_t)kYBlock * cols_per_lane);
+    const double slots = (double)n_cu * ARMON_Y_WAVES * 4 / (block / 64);           // workgroups resident at once
+    const int64_t cols = (nx + 16 + (int64_t)block * cols_per_lane - 1) / ((int64_t)block * cols_per_lane);
     int best = (int)(ny < 32 ? ny : 32);
     double best_cost = 1e300;
     for (int64_t nruns = 1; nruns <= ny; nruns++) {
@@ -1385,6 +1399,14 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.p_out = d->p_out;
     a.c_out = d->c_out;
     a.st = d->dt_state;
+    // the Y march stores through LDS when its rows do not all start on sectors (ARMON_Y_SX: 1 always, 2 never). Tuned
+    // arithmetic only: the exact flavour is bound by its arithmetic (§4.2) and is not instantiated with the exchange.
+    const bool align = ctx->tune_align != 0;
+    a.y_sx = 0;
+    if (!X && align && ctx->tune_y_sx != 2 && !d->exact) {
+        const uintptr_t outs = (uintptr_t)d->rho_out | (uintptr_t)d->u_out | (uintptr_t)d->v_out | (uintptr_t)d->E_out;
+        a.y_sx = outs % 64 == 0 && ((a.row_len * (int64_t)sizeof(real)) % 64 != 0 || ctx->tune_y_sx == 1);
+    }
     if (X) {
         a.seg = 512;
     } else if (ctx->tune_y_seg > 0) {
@@ -1393,9 +1415,10 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
         // the tuned fp32 march holds two columns per lane (k_sweep_y2, same condition as in launch()): half the workgroups per row
         const int cols_per_lane = (std::is_same<real, float>::value && !d->exact && d->nx % 2 == 0 && d->nghost % 2 == 0 &&
                                    d->nx >= 2 && !ctx->tune_y_cols1) ? 2 : 1;
-        if (ctx->seg_nx != d->nx || ctx->seg_ny != n_axis || ctx->seg_lag != lag || ctx->seg_cols != cols_per_lane) {
-            ctx->seg_value = y_run_length(ctx->n_cu, d->nx, n_axis, lag, cols_per_lane);
-            ctx->seg_cols = cols_per_lane;
+        const int y_block = a.y_sx ? kYSxBlock : kYBlock;
+        if (ctx->seg_nx != d->nx || ctx->seg_ny != n_axis || ctx->seg_lag != lag || ctx->seg_cols != cols_per_lane * y_block) {
+            ctx->seg_value = y_run_length(ctx->n_cu, d->nx, n_axis, lag, cols_per_lane, y_block);
+            ctx->seg_cols = cols_per_lane * y_block;
             ctx->seg_nx = d->nx;
             ctx->seg_ny = n_axis;
             ctx->seg_lag = lag;
@@ -1414,16 +1437,9 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
         a.o_lo = d->out_lo;
         a.o_hi = d->out_hi;
     }
-    const bool align = ctx->tune_align != 0;
     a.xshift = (X || !align) ? 0 : d->nghost % 16;
     a.x_first = X ? (align ? a.o_lo - (a.o_lo + d->nghost) % 8 : a.o_lo) : 0;
     a.xcd_remap = ctx->tune_x_xcd;
-    // the Y march stores through LDS when its rows do not all start on sectors (ARMON_Y_SX: 1 always, 2 never)
-    a.y_sx = 0;
-    if (!X && align && ctx->tune_y_sx != 2) {
-        const uintptr_t outs = (uintptr_t)d->rho_out | (uintptr_t)d->u_out | (uintptr_t)d->v_out | (uintptr_t)d->E_out;
-        a.y_sx = outs % 64 == 0 && ((a.row_len * (int64_t)sizeof(real)) % 64 != 0 || ctx->tune_y_sx == 1);
-    }
     // origins row by row when one origin cannot align every row (the one-strip-per-wave form only; the A/B forms keep one)
     a.x_row_align = 0;
 #ifndef ARMON_XS_MULTI
