@@ -77,6 +77,26 @@ def test_other_cases_16384_fused_exact(oracle, test):
         del a
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("test,shape", [("Sod", (16388, 1030)), ("Sod_y", (4099, 8200)), ("Sod", (8187, 2050)), ("Sod_y", (16384, 2048))])
+def test_irregular_row_pitch_keeps_the_axis_invariance(test, shape, dtype):
+    """Row pitches that are not a multiple of a 64-B sector (16396, 4107, 8195 cells; 16392 floats for the last shape in fp32)
+    take the X strip origins row by row and pass the Y march's rows through LDS (column (t - r) mod 512 per thread): Sod must
+    still give the same bits in every ROW although each row has its own origin, Sod_y in every COLUMN although the march
+    rotates them — at sizes with several strips, workgroups and runs, tuned arithmetic (the form that carries the exchange)."""
+    import armon_amd
+    params = armon_amd.ArmonParameters(test=test, N=shape, maxcycle=CYCLES, silent=5, exact_arithmetic=False, return_data=True,
+                                       data_type=dtype)
+    stats = armon_amd.armon(params)
+    assert stats.cycles == CYCLES and np.isfinite(stats.last_dt)
+    for k in NAMES:
+        a = stats.data.real_view(stats.data.data[k].to_host())
+        line = a[0:1] if test == "Sod" else a[:, 0:1]
+        assert np.array_equal(a, np.broadcast_to(line, a.shape)), f"{k}: lines differ"
+        assert np.isfinite(a).all()
+        del a
+
+
 def test_sod_4096_full_run_to_maxtime():
     """A whole physical run (t = 0.2, ≈1900 cycles, tuned arithmetic, deferred dt read-back all the way): mass and
     energy conserved to 1e-12 relative (ref test/conservation.jl's bound is 1e-12 absolute at 100²), rows identical."""
