@@ -118,13 +118,19 @@ k_acoustic_GAD(armon_range r, int64_t s, T dt, T dx, T* __restrict__ us,
 // The reference's kernel above solves every interface three times (once as "its own", twice as a neighbour's:
 // ref src/riemann_schemes.jl:63-80). The two forms below compute the same values from the same operands — bit for bit
 // the same results — but solve each interface ONCE and hand the solutions to the neighbours:
-//  * sweep along x (s == 1): lanes along x, a wave covers 64 consecutive cells of which the two outer ones are halo
+//  * sweep along x (s == 1): lanes along x, a wave covers 64 consecutive cells of which the outer ones are halo
 //    lanes (they only contribute their interface solution); neighbours' cells and solutions come from DPP wavefront
-//    shifts. 62 fluxes per 64 solves.
+//    shifts. The stencil needs one halo lane on either side (62 fluxes per 64 solves); a wave takes 4 + 4 (fp64) and
+//    produces 56 fluxes = 7 whole 64-B sectors, placed on the sectors of the array: a wave that begins and ends its
+//    stores inside a sector pays for it (2.34-2.39 -> 2.19 ms at 16384², profiles/r03_gad_forms.txt; the misplaced
+//    LOADS cost nothing, profiles/r03_row_pitch_repairs.txt).
 //  * sweep along y (s == row pitch of the range): lane ↔ column, each thread walks kGadRows rows with a rolling
 //    window of the last two cells and three solutions. kGadRows fluxes per kGadRows + 2 solves.
 // No cell outside the reference's own stencil [i - 2s, i + s] of the range is read.
 constexpr int kGadValid = 62;
+#ifndef ARMON_GAD_ALIGNED
+#define ARMON_GAD_ALIGNED 1      // x forms (GAD, second-order advection): 1 = waves that store whole sectors (56 of 64 lanes in fp64), 0 = 62 / 60
+#endif
 #ifndef ARMON_GAD_ROWS
 #define ARMON_GAD_ROWS 64        // rows per thread of the y form (tuning macro)
 #endif
@@ -142,16 +148,28 @@ k_acoustic_GAD_x(armon_range r, T dt, T dx, T* __restrict__ us, T* __restrict__ 
     using fused::from_next_lane;
     using fused::from_prev_lane;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if ARMON_GAD_ALIGNED
+    // a wave stores whole 64-B sectors: 64 - S fluxes (S = cells per sector), S/2 halo lanes on either side, the first wave
+    // of a row starting on the sector at or below the row's first flux
+    constexpr int kS = 64 / (int)sizeof(T), kLeft = kS / 2, kValid = 64 - kS;
+    const int64_t w0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kValid - ((r.col_start + r.row_start) & (kS - 1));
+    const int64_t k = w0 + lane - kLeft;
+    const bool has_cell = k >= -2 && k <= r.row_len;           // the reference's stencil of the range
+    const bool stores = lane >= kLeft && lane < kLeft + kValid && k >= 0 && k < r.row_len;
+    if (w0 >= r.row_len) return;                               // whole wave past the row
+#else
+    constexpr int kLeft = 1;
     const int64_t k = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kGadValid + lane - 1;   // lanes 0 and 63: halo
     const bool has_cell = k >= -1 && k <= r.row_len;           // the halo lanes may sit one cell outside the row
     const bool stores = lane >= 1 && lane <= kGadValid && k < r.row_len;
     if (((int64_t)blockIdx.x * (kBlock / 64) + wave) * kGadValid >= r.row_len) return;      // whole wave past the row
+#endif
     for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
         const int64_t i = row_base(r, j) + k;
         T rho_i = 1, c_i = 1, u_i = 0, p_i = 1;
         if (has_cell) { rho_i = rho[i]; c_i = c[i]; u_i = u[i]; p_i = p[i]; }
         T rho_m = from_prev_lane(rho_i), c_m = from_prev_lane(c_i), u_m = from_prev_lane(u_i), p_m = from_prev_lane(p_i);
-        if (lane == 0) {                                        // no lane to the left: its cell i - 1 from memory
+        if (kLeft == 1 && lane == 0) {                          // no lane to the left: its cell i - 1 from memory
             rho_m = 1; c_m = 1; u_m = 0; p_m = 1;
             if (has_cell) { rho_m = rho[i - 1]; c_m = c[i - 1]; u_m = u[i - 1]; p_m = p[i - 1]; }
         }
@@ -405,12 +423,19 @@ k_advection_second_order_x(armon_range r, T dx, T dt, const T* __restrict__ us, 
     using fused::from_next_lane;
     using fused::from_prev_lane;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if ARMON_GAD_ALIGNED
+    // whole-sector stores, as in k_acoustic_GAD_x: 64 - S interfaces per wave, S/2 halo lanes on either side (2 are needed)
+    constexpr int kS = 64 / (int)sizeof(T), kLeft = kS / 2, kValid = 64 - kS;
+    const int64_t w0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kValid - ((r.col_start + r.row_start) & (kS - 1));
+#else
+    constexpr int kLeft = 2, kValid = kAdvValid;                                      // lanes 0,1 and 62,63: halo
     const int64_t w0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kAdvValid;      // first interface of this wave
+#endif
     if (w0 >= r.row_len) return;
-    const int64_t k = w0 + lane - 2;                                                  // lanes 0,1 and 62,63: halo
+    const int64_t k = w0 + lane - kLeft;
     const bool has_us = k >= -2 && k <= r.row_len + 1;
     const bool has_cell = k >= -2 && k <= r.row_len;                                  // ρ,u,v,E are read up to is + s only
-    const bool stores = lane >= 2 && lane < 2 + kAdvValid && k < r.row_len;
+    const bool stores = lane >= kLeft && lane < kLeft + kValid && k >= 0 && k < r.row_len;
     for (int64_t j = blockIdx.y; j < r.col_len; j += gridDim.y) {
         const int64_t i = row_base(r, j) + k;
         const T us_c = has_us ? us[i] : T(0);
@@ -684,6 +709,12 @@ int acoustic_GAD_impl(armon_ctx* ctx, armon_range r, int64_t s, T dt, T dx, T* u
     // reference's own shape (any other stride)
     int form = (s == 1) ? 1 : ((s == r.col_step && r.col_len > 1) ? 2 : 0);
     if (form == 1) grid.x = (unsigned)(((r.row_len + kGadValid - 1) / kGadValid + kBlock / 64 - 1) / (kBlock / 64));   // waves of 62 fluxes
+#if ARMON_GAD_ALIGNED
+    if (form == 1) {
+        const int64_t S = 64 / (int64_t)sizeof(T), valid = 64 - S;
+        grid.x = (unsigned)(((r.row_len + ((r.col_start + r.row_start) & (S - 1)) + valid - 1) / valid + kBlock / 64 - 1) / (kBlock / 64));
+    }
+#endif
 #if ARMON_GAD_X2
     if (form == 1 && sizeof(T) == 8 && r.col_step % 2 == 0 &&
         ((uintptr_t)us | (uintptr_t)ps | (uintptr_t)rho | (uintptr_t)ua | (uintptr_t)p | (uintptr_t)c) % 16 == 0) {
@@ -758,6 +789,12 @@ int advection_second_order_impl(armon_ctx* ctx, armon_range r, int64_t s, T dx, 
     range_grid(r, 1, grid, block);
     if (s == 1) {                                         // lanes along the sweep: 60 interfaces per wave
         grid.x = (unsigned)(((r.row_len + kAdvValid - 1) / kAdvValid + kBlock / 64 - 1) / (kBlock / 64));
+#if ARMON_GAD_ALIGNED
+        {
+            const int64_t S = 64 / (int64_t)sizeof(T), valid = 64 - S;
+            grid.x = (unsigned)(((r.row_len + ((r.col_start + r.row_start) & (S - 1)) + valid - 1) / valid + kBlock / 64 - 1) / (kBlock / 64));
+        }
+#endif
         hipLaunchKernelGGL(k_advection_second_order_x<T>, grid, block, 0, ctx->stream, r, dx, dt, us, rho, u,
                            v, E, a_rho, a_urho, a_vrho, a_Erho);
     } else if (s == r.col_step && r.col_len > 1) {        // march along the sweep
