@@ -3,7 +3,8 @@
 // 4 rows prefetched. The pitch of the read arrays and of the written arrays are set separately (which side pays?), and
 // two repairs are timed: LX — every row is LOADED in sector-aligned windows (thread t takes column (t - r) mod 256 of
 // the workgroup, r = the row's phase in cells) and handed to its owner through LDS; SX — the same for the STORES.
-// One barrier per row serves both (double-buffered LDS).
+// One barrier per row serves both (double-buffered LDS). SX=2: after the hand-over wave w stores the workgroup's whole row
+// of array w (2 KB contiguous, 16 B per lane) instead of 512 B of each of the four arrays.
 //   hipcc -O3 --offload-arch=gfx950 -o probe_ypitch probe_ypitch.hip && ./probe_ypitch
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -15,10 +16,11 @@
 struct ptrs { const double* in[4]; double* out[4]; };
 constexpr int LAG = 4, PF = 4, BLOCK = 256;
 
-template <bool LX, bool SX>
+template <bool LX, int SXM>
 __global__ __launch_bounds__(BLOCK) void ypat(ptrs p, int nx, int ny, int g, long pitch_in, long pitch_out, int seg, int shift)
 {
-    __shared__ double lds[2][2][4][BLOCK];                    // [buffer][load / store side][array][column of the workgroup]
+    constexpr bool SX = SXM != 0;
+    __shared__ __attribute__((aligned(16))) double lds[2][2][4][BLOCK];                    // [buffer][load / store side][array][column of the workgroup]
     const int t = threadIdx.x;
     const int c0 = blockIdx.x * BLOCK - shift;               // first column of the workgroup (may be < 0: ghost side)
     const int o0 = blockIdx.y * seg, o1 = min(o0 + seg, ny);
@@ -63,7 +65,24 @@ __global__ __launch_bounds__(BLOCK) void ypat(ptrs p, int nx, int ny, int g, lon
                     for (int k = 0; k < 4; k++) ring[ph & 7][k] = lds[buf][0][k][t];     // the owner's own column
                 }
             }
-            if (produce) {
+            if (produce && SXM == 2) {
+                // wave w stores the whole workgroup row of array w: 2 KB contiguous, 16 B per lane and instruction
+                // (sector-aligned pitches only: the row starts on a sector, pairs never straddle the row's ends here)
+                typedef double v2 __attribute__((ext_vector_type(2)));
+                const int w = t >> 6, lane = t & 63;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int ci = h * 128 + lane * 2;
+                    const int c = c0 + ci;
+                    if (c >= 0 && c + 1 < nx) {
+                        const v2 v = *reinterpret_cast<const v2*>(&lds[buf][1][w][ci]);
+                        __builtin_nontemporal_store(v, reinterpret_cast<v2*>(p.out[w] + rbo + ci));
+                    } else {
+                        if (c >= 0 && c < nx) __builtin_nontemporal_store(lds[buf][1][w][ci], p.out[w] + rbo + ci);
+                        if (c + 1 >= 0 && c + 1 < nx) __builtin_nontemporal_store(lds[buf][1][w][ci + 1], p.out[w] + rbo + ci + 1);
+                    }
+                }
+            } else if (produce) {
                 int ci = t;
                 if (SX) ci = (t - (int)(rbo & 7)) & (BLOCK - 1);
                 const int c = c0 + ci;
@@ -121,22 +140,29 @@ int main()
     const int seg = 1024, shift = 4;
     dim3 grid((nx + shift + BLOCK - 1) / BLOCK, (ny + seg - 1) / seg);
 #define RUN(LX, SX, pin, pout) { \
-        snprintf(tag, sizeof tag, "Y march  pitch in %ld (mod 8: %ld)  out %ld (mod 8: %ld)  LX=%d SX=%d", (long)(pin), (long)(pin) % 8, (long)(pout), (long)(pout) % 8, LX, SX); \
+        snprintf(tag, sizeof tag, "Y march  pitch in %ld (mod 8: %ld)  out %ld (mod 8: %ld)  LX=%d SX=%d", (long)(pin), (long)(pin) % 8, (long)(pout), (long)(pout) % 8, (int)LX, (int)SX); \
         if (timeit(tag, bytes, [&] { ypat<LX, SX><<<grid, BLOCK>>>(p, nx, ny, g, pin, pout, seg, shift); })) return 1; }
     const long P0 = nx + 2 * g;
-    RUN(false, false, P0, P0)
-    RUN(false, false, P0 + 4, P0)
-    RUN(false, false, P0, P0 + 4)
-    RUN(false, false, P0 + 4, P0 + 4)
-    RUN(false, false, P0 + 3, P0)
-    RUN(false, false, P0, P0 + 3)
-    RUN(false, false, P0 + 3, P0 + 3)
-    RUN(true, true, P0, P0)
-    RUN(true, false, P0 + 4, P0)
-    RUN(false, true, P0, P0 + 4)
-    RUN(true, true, P0 + 4, P0 + 4)
-    RUN(true, false, P0 + 3, P0)
-    RUN(false, true, P0, P0 + 3)
-    RUN(true, true, P0 + 3, P0 + 3)
+    RUN(false, 0, P0, P0)
+    RUN(false, 0, P0 + 4, P0)
+    RUN(false, 0, P0, P0 + 4)
+    RUN(false, 0, P0 + 4, P0 + 4)
+    RUN(false, 0, P0 + 3, P0)
+    RUN(false, 0, P0, P0 + 3)
+    RUN(false, 0, P0 + 3, P0 + 3)
+    RUN(true, 1, P0, P0)
+    RUN(true, 0, P0 + 4, P0)
+    RUN(false, 1, P0, P0 + 4)
+    RUN(true, 1, P0 + 4, P0 + 4)
+    RUN(true, 0, P0 + 3, P0)
+    RUN(false, 1, P0, P0 + 3)
+    RUN(true, 1, P0 + 3, P0 + 3)
+    // sector-aligned pitch: plain, per-thread hand-over, one array per wave with 16-B stores (SX=2), twice each
+    RUN(false, 0, P0, P0)
+    RUN(false, 1, P0, P0)
+    RUN(false, 2, P0, P0)
+    RUN(false, 0, P0, P0)
+    RUN(false, 1, P0, P0)
+    RUN(false, 2, P0, P0)
     return 0;
 }
