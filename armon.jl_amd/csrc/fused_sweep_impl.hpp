@@ -672,7 +672,9 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     // lane pair then sits on 16 B (fp32: 8 B) whatever the parity of the pitch.
     int64_t x_first = a.x_first;
     if (ROW == 0 && a.x_row_align) {
-        x_first = a.o_lo - ((row_off + a.o_lo) & (64 / (int)sizeof(real) - 1));
+        // (a wave's row is uniform, which the compiler cannot know: without readfirstlane every strip index below becomes
+        // 64-bit vector arithmetic — +3 % on the VALU-bound exact flavour)
+        x_first = a.o_lo - __builtin_amdgcn_readfirstlane((int)(row_off + a.o_lo) & (64 / (int)sizeof(real) - 1));
         vec_ok = (K == 2);
     }
 
