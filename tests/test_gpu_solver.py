@@ -657,3 +657,37 @@ def test_animation_frames_and_slices(tmp_path, fused):
     load = lambda tag: np.array([[float(t) for t in line.split(",")] for line in open(tmp_path / f"run_{tag}")])
     assert np.array_equal(load("X"), cols[N[1] // 2]) and np.array_equal(load("Y"), cols[:, N[0] // 2])
     assert np.array_equal(load("diag"), np.array([cols[k, k] for k in range(min(N))]))
+
+
+@pytest.mark.parametrize("dtype,offset", [("float64", 8), ("float64", 32), ("float32", 4), ("float32", 40)])
+@pytest.mark.parametrize("N", [(333, 300), (328, 300), (700, 64)])
+def test_vectors_that_do_not_start_on_a_sector(N, dtype, offset):
+    """Arrays handed over as views into larger allocations (8 … 40 bytes past a 64-B sector): the sector-aligned forms
+    (row-by-row strip origins, the Y march's LDS hand-over, 16-B accesses) must step aside for the plain ones — same bits
+    as on ordinary allocations."""
+    import armon_amd
+    from armon_amd.device import DeviceArray
+    from armon_amd.solver import BlockGrid, init_test, time_loop
+    opts = dict(test="Sod_circ", N=N, maxcycle=6, silent=5, exact_arithmetic=False, data_type=dtype)
+    results = []
+    for shifted in (False, True):
+        params = armon_amd.ArmonParameters(**opts)
+        grid = BlockGrid(params)
+        owners = []
+        if shifted:
+            def shifted_view(v):
+                big = params.device.empty(v.n + 64, v.dtype)
+                owners.append(big)
+                a = DeviceArray.__new__(DeviceArray)
+                a.device, a.n, a.dtype, a.nbytes = big.device, v.n, v.dtype, v.nbytes
+                a.ptr, a.owner = big.ptr + offset, big
+                return a
+            grid.data = {f: shifted_view(v) for f, v in grid.data.items()}
+            grid.alt = {f: shifted_view(v) for f, v in grid.alt.items()}
+        init_test(params, grid)
+        _t, dt, cycles, _, _ = time_loop(params, grid)
+        results.append((cycles, dt, {k: grid.real_view(grid.data[k].to_host()).copy() for k in ("rho", "u", "v", "E")}))
+        del grid, owners
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    for k in results[0][2]:
+        assert np.array_equal(results[0][2][k], results[1][2][k]), k
