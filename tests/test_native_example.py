@@ -30,6 +30,7 @@ def build_example(tmp_path, name="native_cycle"):
 def test_native_example_builds(tmp_path):
     build_example(tmp_path)
     build_example(tmp_path, "native_tiles")
+    build_example(tmp_path, "native_graph")
 
 
 @pytest.mark.gpu
@@ -74,3 +75,15 @@ def test_native_tiles_example_matches_the_python_tile_group(tmp_path, n, px, py)
         group.close()
     assert (m0, e0) == (pm0, pe0)
     assert (m1, e1) == (pm1, pe1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cycles", [(640, 40), (129, 7), (1000, 2)])
+def test_native_graph_example_replays_the_host_driven_run(tmp_path, n, cycles):
+    """examples/native_graph.c — armon_dt_state, auto_step and armon_hip_graph_* from plain C: the run whose time step never
+    leaves the device, one captured cycle replayed per call (three replays past the end included), must end on the bits of
+    the host-driven loop: time, next dt, cycle count, mass and energy."""
+    res = subprocess.run([build_example(tmp_path, "native_graph"), str(n), str(cycles)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "identical: yes" in res.stdout, res.stdout
+    assert re.search(r"cycle %d, done 1" % cycles, res.stdout), res.stdout
