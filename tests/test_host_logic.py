@@ -169,6 +169,23 @@ def test_reference_cpu_options_are_accepted():
 
 
 # ---- dt state machine (ref src/solver_state.jl:102-166) ------------------------------------------
+@pytest.mark.parametrize("N", [(7, 38), (514, 238), (50, 50), (120, 200), (333, 77)])
+def test_sedov_radius_in_float32_is_evaluated_as_the_reference_does(N):
+    """ref src/tests.jl:13-19: ``r::T = hypot(Δx...) / sqrt(2)`` — hypot in T, the division in Float64, then the conversion to
+    T. numpy 2 would keep ``float32 / python_float`` in float32 (one ulp off on non-square cells); the oracle's C evaluation
+    (float hypotf, double division) is the reference's."""
+    from armon_amd.test_cases import create_test
+    from oracle import oracle
+    T = np.float32
+    dX = (T(2) / T(N[0]), T(2) / T(N[1]))
+    r = create_test("Sedov", dX, T).r
+    assert r == float(T(float(np.hypot(dX[0], dX[1])) / math.sqrt(2.0)))
+    # the oracle's initial state holds the same radius: the energy of its high region is T((1/1.033)^5 / (π r²))
+    run, f = oracle.solve(test="Sedov", N=N, maxcycle=0, data_type=np.float32)
+    e_hi = oracle.real_view(f["E"], N[0], N[1], 4).max()
+    assert e_hi == T(math.pow(1. / 1.033, 5) / float(T(T(math.pi) * T(T(r) * T(r)))))
+
+
 def test_global_time_step_lag_and_growth_cap():
     p = ArmonParameters(test="Sod", N=(8, 8), cfl=0.5)
     g = GlobalTimeStep(p)
