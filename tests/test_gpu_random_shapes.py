@@ -1,7 +1,8 @@
 """Seeded random sweep over block shapes, ghost widths and option combinations: whatever the row pitch does to the strip
 origins (row by row when the pitch is not a multiple of a 64-B sector), the wave / workgroup / run boundaries and the Y
 march's store windows, the fused sweeps in exact arithmetic must give the oracle's bits, and the tuned arithmetic must give
-the same bits with the LDS store exchange forced on, forced off and automatic, within its tolerance of the oracle.
+the same bits with the LDS store exchange forced on, forced off and automatic — and with the cycle replayed from a graph —,
+within its tolerance of the oracle; the staged kernels must give the oracle's bits as well.
 The fixed lists of tests/test_gpu_solver.py pick the shapes by hand; this one draws them."""
 import os
 import random
@@ -74,6 +75,11 @@ def test_random_shape_exact_equals_the_oracle_and_tuned_ignores_the_store_exchan
     assert stats.cycles == orun.cycles and stats.last_dt == orun.last_dt and stats.final_time == orun.final_time
     for k in NAMES:
         assert same_bits_outside_the_subnormal_range(got[k], ref[k]), f"exact {k}: max abs diff {np.abs(got[k] - ref[k]).max()}"
+    # the staged kernels (the reference-shaped path): the oracle's bits too
+    stats, got = gpu_run(dtype, True, use_fused_sweep=False, **case)
+    assert stats.cycles == orun.cycles and stats.last_dt == orun.last_dt and stats.final_time == orun.final_time
+    for k in NAMES:
+        assert same_bits_outside_the_subnormal_range(got[k], ref[k]), f"staged {k}: max abs diff {np.abs(got[k] - ref[k]).max()}"
     # tuned arithmetic: the same bits whoever stores a cell, and the oracle within the tuned tolerance
     monkeypatch.setenv("ARMON_Y_SX", "2")
     s0, t0 = gpu_run(dtype, False, **case)
@@ -83,6 +89,12 @@ def test_random_shape_exact_equals_the_oracle_and_tuned_ignores_the_store_exchan
         assert s1.cycles == s0.cycles and s1.last_dt == s0.last_dt
         for k in NAMES:
             assert np.array_equal(t1[k], t0[k]), (mode, k)
+    # … and whoever drives the loop: the time step on the device, the cycle replayed from a graph
+    monkeypatch.setenv("ARMON_Y_SX", "0")
+    s2, t2 = gpu_run(dtype, False, graph_cycles=True, **case)
+    assert s2.cycles == s0.cycles and s2.last_dt == s0.last_dt and s2.final_time == s0.final_time
+    for k in NAMES:
+        assert np.array_equal(t2[k], t0[k]), ("graph", k)
     assert s0.cycles == orun.cycles
     tol = 1e-11 if dtype == "float64" else 2e-4
     assert abs(s0.last_dt - orun.last_dt) <= (1e-12 if dtype == "float64" else 1e-5) * orun.last_dt
