@@ -227,6 +227,41 @@ def test_advection(dev, L, oracle, shape, axis, order):
     assert_same(d, f, ("work_1", "work_2", "work_3", "work_4"))
 
 
+def _random_flux_cases(seed, count):
+    import random
+    rng = random.Random(seed)
+    cases = []
+    for _ in range(count):
+        nx, ny = rng.randint(1, 600), rng.randint(1, 90)
+        # a range inside the block whose stencil (2 cells below, 2 above along the sweep) stays inside the ghosted arrays
+        lo = rng.randint(-2, min(3, nx - 1))
+        hi = rng.randint(-min(3, nx - 1 - max(lo, 0)), 2)
+        cases.append((nx, ny, lo, hi, rng.randint(0, 1), rng.randint(0, 2), rng.randint(0, 10 ** 6)))
+    return cases
+
+
+@pytest.mark.parametrize("nx,ny,lo,hi,axis,limiter,seed", _random_flux_cases(4242, 40))
+def test_flux_kernels_on_random_ranges(dev, L, oracle, nx, ny, lo, hi, axis, limiter, seed):
+    """acoustic_GAD and advection_second_order on drawn shapes and ranges (first / last cell anywhere within the ghost
+    stencil, along x and along y): the wave layouts of the x forms (56 results + 4 + 4 halo lanes, placed on the sectors of
+    the array) and the marches of the y forms must write the oracle's bits inside the range and nothing outside it."""
+    if axis == 1:
+        nx, ny = ny, nx
+    f = rand_state(nx, ny, seed)
+    d = upload(dev, f)
+    bl, tr = ((lo, 0), (hi, 0)) if axis == 0 else ((0, lo), (0, hi))
+    r = oracle.domain_range(nx, ny, G, bl, tr)
+    s = 1 if axis == 0 else nx + 2 * G
+    ua = "u" if axis == 0 else "v"
+    dt, dx = 1e-3, 1.0 / max(nx, ny)
+    oracle.lib().armon_oracle_acoustic_GAD(r, s, dt, dx, *(oracle.ptr(f[k]) for k in ("us", "ps", "rho", ua, "p", "c")), limiter)
+    assert L.armon_hip_acoustic_GAD(dev.ctx, conv(r), s, dt, dx, *(P(d, k) for k in ("us", "ps", "rho", ua, "p", "c")), limiter) == 0
+    assert_same(d, f, ("us", "ps"))
+    oracle.lib().armon_oracle_advection_second_order(r, s, dx, dt, *(oracle.ptr(f[k]) for k in ADV))
+    assert L.armon_hip_advection_second_order(dev.ctx, conv(r), s, dx, dt, *(P(d, k) for k in ADV)) == 0
+    assert_same(d, f, ("work_1", "work_2", "work_3", "work_4"))
+
+
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_euler_projection(dev, L, oracle, shape, axis):
