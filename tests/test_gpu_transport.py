@@ -9,6 +9,8 @@
 Replaces ref src/halo_exchange.jl:229-283 (MPI.Start / MPI.Wait of the persistent requests) and src/solver_state.jl:89-111.
 What a multi-GPU node adds to these is a peer that is another device; the calls, their stream ordering and the buffer
 protocol are the ones run here."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,6 +88,50 @@ def test_doubly_periodic_run_is_the_same_through_every_transport(tmp_path, oracl
                 assert np.array_equal(got[k], t[k]), (P, force, k)
         finally:
             group.close()
+
+
+def _random_periodic_cases(seed, count):
+    import random
+    rng = random.Random(seed)
+    cases = []
+    for _ in range(count):
+        scheme = rng.choice(["GAD", "GAD", "Godunov"])
+        projection = rng.choice(["euler_2nd", "euler_2nd", "euler"])
+        lag = 2 + (scheme == "GAD") + (projection == "euler_2nd")
+        P = rng.choice([(1, 1), (2, 1), (1, 2), (2, 2), (3, 2)])
+        N = (rng.randint(P[0] * 8, P[0] * 60), rng.randint(P[1] * 8, P[1] * 50))
+        cases.append(dict(P=P, N=N, test=rng.choice(["Sod_circ", "Sedov", "Bizarrium"]), periodic=rng.choice([(True, True), (True, False), (False, True)]),
+                          force=rng.random() < 0.6, fused=rng.random() < 0.75,
+                          opts=dict(scheme=scheme, projection=projection, nghost=max(lag, rng.choice([lag, 4, 6])), maxcycle=rng.randint(3, 7),
+                                    axis_splitting=rng.choice(["Sequential", "Godunov", "Strang"]))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_periodic_cases(int(os.environ.get("ARMON_RANDOM_SEED", "2718")), int(os.environ.get("ARMON_RANDOM_CASES", "8"))),
+                         ids=lambda c: f"{c['P'][0]}x{c['P'][1]}-{c['test']}-{c['N'][0]}x{c['N'][1]}-per{int(c['periodic'][0])}{int(c['periodic'][1])}-{'peer' if c['force'] else 'direct'}-{'fused' if c['fused'] else 'staged'}")
+def test_random_periodic_runs_through_rccl_and_peer_copies(tmp_path, oracle, case):
+    """Drawn shapes, ghost widths, options and periodic axes: the 1 x 1 rank over RCCL (ncclSend / ncclRecv to itself on the
+    periodic axes) and a drawn in-process tile group (plain or forced peer copies) must both give the periodic oracle's bits."""
+    from armon_amd.multi_tile import TileGroup
+    N, test, periodic = case["N"], case["test"], case["periodic"]
+    o = dict(case["opts"], use_fused_sweep=case["fused"], exact_arithmetic=True)
+    g = o["nghost"]
+    orun, f = oracle.solve(test=test, N=N, periodic=periodic, **case["opts"])
+    ref = {k: oracle.real_view(f[k], N[0], N[1], g) for k in ("rho", "u", "v", "E", "p")}
+    spawn(dist_workers.rccl_periodic_worker, 1, "run", N, test, dict(o, periodic=periodic), str(tmp_path))
+    t = np.load(tmp_path / "tile0.npz")
+    assert int(t["cycles"]) == orun.cycles and float(t["dt"]) == orun.last_dt and float(t["time"]) == orun.final_time
+    for k in ref:
+        assert np.array_equal(t[k], ref[k]), ("rccl", k)
+    group = TileGroup(case["P"], test=test, N=N, silent=5, periodic=periodic, force_peer_copy=case["force"], **o)
+    try:
+        stats = group.run()
+        got = group.gather()
+        assert stats.cycles == orun.cycles and stats.last_dt == orun.last_dt and stats.final_time == orun.final_time
+        for k in ref:
+            assert np.array_equal(got[k], ref[k]), ("group", k)
+    finally:
+        group.close()
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["staged", "fused"])
