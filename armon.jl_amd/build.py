@@ -11,9 +11,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libarmon_hip.so")
 # A/B build: the product library + the measured-and-rejected kernel forms (-DARMON_ALT_KERNELS: whole-cycle kernels, LDS X
-# march, one-cell-per-lane DPP sweep). Only the tests and tools that exercise those forms load it.
+# march, one-cell-per-lane DPP sweep) + the exact arithmetic in its strict form (-DARMON_STRICT_SUBNORMAL: quotients that can
+# fall below the normal range take the IEEE expansion, -5 % on the exact sweeps; csrc/physics.hpp). Only the tests and tools
+# that exercise those load it.
 OUT_ALT = os.path.join(HERE, "libarmon_hip_alt.so")
-ALT_SOURCES = ("fused_sweep_f64.hip", "fused_sweep_f32.hip")     # the translation units the define changes
+ALT_SOURCES = ("fused_sweep_f64.hip", "fused_sweep_f32.hip", "staged_kernels.hip")     # the translation units the defines change
+ALT_FLAGS = ["-DARMON_ALT_KERNELS", "-DARMON_STRICT_SUBNORMAL"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: the "exact" kernels must evaluate one IEEE op per source op (bit parity with the
@@ -52,7 +55,7 @@ def build(force=False, verbose=False, alt=True):
         if alt and src in ALT_SOURCES:
             obj_alt = os.path.join(HERE, "build", src[:-4] + "_alt.o")
             if force or _stale(obj_alt, [os.path.join(CSRC, src)] + hdrs + [__file__]):
-                jobs.append([HIPCC, *CXXFLAGS, "-DARMON_ALT_KERNELS", "-c", os.path.join(CSRC, src), "-o", obj_alt])
+                jobs.append([HIPCC, *CXXFLAGS, *ALT_FLAGS, "-c", os.path.join(CSRC, src), "-o", obj_alt])
             obj = obj_alt
         objs_alt.append(obj)
 

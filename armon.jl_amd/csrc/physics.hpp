@@ -34,6 +34,7 @@ template <> struct Den<float> {
     __device__ __forceinline__ Den() : b(1.f) {}
     __device__ __forceinline__ explicit Den(float b_) : b(b_) {}
     __device__ __forceinline__ float quo(float a) const { return a / b; }
+    __device__ __forceinline__ float quo_t(float a) const { return a / b; }
     __device__ __forceinline__ Den twice() const { return Den(2.f * b); }
 };
 
@@ -43,6 +44,7 @@ template <> struct Den<double> {
     __device__ __forceinline__ Den() : b(1.) {}
     __device__ __forceinline__ explicit Den(double b_) : b(b_) {}
     __device__ __forceinline__ double quo(double a) const { return a / b; }
+    __device__ __forceinline__ double quo_t(double a) const { return a / b; }
     __device__ __forceinline__ Den twice() const { return Den(2. * b); }
 };
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
@@ -63,6 +65,21 @@ template <> struct Den<double> {
         const double q = a * r;
         const double rem = __builtin_fma(-b, q, a);
         return __builtin_fma(rem, r, q);
+    }
+    // a / b where the quotient may fall below the normal range — the velocities of a fluid at rest, their fluxes and slope
+    // ratios (Sedov's far field carries 1e-320). There quo()'s remainder step underflows and the result can be one unit of
+    // the subnormal grid (4.9e-324) off an IEEE division: the ONE stated exception to the bit parity of the exact flavour
+    // (1 run in 800 of tests/test_gpu_random_shapes.py). -DARMON_STRICT_SUBNORMAL sends the rare tiny
+    // quotient through the IEEE expansion instead — every bit then, for 5 % of the VALU-bound exact sweeps (seven guarded
+    // quotients per cell); the A/B library is built that way and the random sweep holds it to strict equality.
+    __device__ __forceinline__ double quo_t(double a) const
+    {
+        const double q = quo(a);
+#ifdef ARMON_STRICT_SUBNORMAL
+        // (an exact zero — the transverse velocity of Sod, a fluid at rest — is the same zero either way and stays on the fast path)
+        if (__builtin_expect(__builtin_fabs(q) < 0x1p-960 && a != 0., 0)) return a / b;
+#endif
+        return q;
     }
     __device__ __forceinline__ Den twice() const                // the denominator 2·b (exact scaling)
     {
@@ -174,7 +191,7 @@ __device__ __forceinline__ void godunov(T rho_i, T rho_m, T c_i, T c_m, T u_i, T
     T rc_l = rho_m * c_m;
     T rc_r = rho_i * c_i;
     const Den<T> d(rc_l + rc_r);                  // one denominator, two quotients
-    us = d.quo(rc_l * u_m + rc_r * u_i + (p_m - p_i));
+    us = d.quo_t(rc_l * u_m + rc_r * u_i + (p_m - p_i));
     ps = d.quo(rc_r * p_m + rc_l * p_i + rc_l * rc_r * (u_m - u_i));
 }
 
@@ -196,9 +213,9 @@ __device__ __forceinline__ void gad_flux(T dt, T dx,
                                          T us_m, T ps_m, T us_0, T ps_0, T us_p, T ps_p,
                                          T& us, T& ps)
 {
-    T r_um = Den<T>(us_0 - u_m + T(1e-6)).quo(us_p - u_i);
+    T r_um = Den<T>(us_0 - u_m + T(1e-6)).quo_t(us_p - u_i);
     T r_pm = Den<T>(ps_0 - p_m + T(1e-6)).quo(ps_p - p_i);
-    T r_up = Den<T>(u_i - us_0 + T(1e-6)).quo(u_m - us_m);
+    T r_up = Den<T>(u_i - us_0 + T(1e-6)).quo_t(u_m - us_m);
     T r_pp = Den<T>(p_i - ps_0 + T(1e-6)).quo(p_m - ps_m);
 
     r_um = limiter<LIM>(r_um);
@@ -249,13 +266,13 @@ __device__ __forceinline__ void euler_projection(T dx, T dt, T us_i, T us_n,
     T dX = dx + dt * (us_n - us_i);
     const Den<T> d_dx(dx);
     T t_rho  = d_dx.quo(dX * rho     - (a_rho_n  - a_rho_i));
-    T t_urho = d_dx.quo(dX * rho * u - (a_urho_n - a_urho_i));
-    T t_vrho = d_dx.quo(dX * rho * v - (a_vrho_n - a_vrho_i));
+    T t_urho = d_dx.quo_t(dX * rho * u - (a_urho_n - a_urho_i));
+    T t_vrho = d_dx.quo_t(dX * rho * v - (a_vrho_n - a_vrho_i));
     T t_Erho = d_dx.quo(dX * rho * E - (a_Erho_n - a_Erho_i));
     const Den<T> d_rho(t_rho);
     rho = t_rho;
-    u = d_rho.quo(t_urho);
-    v = d_rho.quo(t_vrho);
+    u = d_rho.quo_t(t_urho);
+    v = d_rho.quo_t(t_vrho);
     E = d_rho.quo(t_Erho);
 }
 

@@ -125,7 +125,7 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         {
             const T rc_l = c1.rc, rc_r = c0.rc;
             const Den d(rc_l + rc_r);
-            gus[R0] = d.quo(rc_l * c1.ua + rc_r * c0.ua + (c1.p - c0.p));
+            gus[R0] = d.quo_t(rc_l * c1.ua + rc_r * c0.ua + (c1.p - c0.p));
             gps[R0] = d.quo(rc_r * c1.p + rc_l * c0.p + rc_l * rc_r * (c1.ua - c0.ua));
         }
 
@@ -133,9 +133,9 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         if (S == 1) {
             // acoustic_GAD! at interface i = j-1: cells i-s = c2, i = c1 (ref src/riemann_schemes.jl:84-104)
             const T gus0 = gus[R0], gps0 = gps[R0], gus1 = gus[R1], gps1 = gps[R1], gus2 = gus[R2], gps2 = gps[R2];
-            const T r_um = phys::limiter<LIM>(Den(gus1 - c2.ua + T(1e-6)).quo(gus0 - c1.ua));
+            const T r_um = phys::limiter<LIM>(Den(gus1 - c2.ua + T(1e-6)).quo_t(gus0 - c1.ua));
             const T r_pm = phys::limiter<LIM>(Den(gps1 - c2.p + T(1e-6)).quo(gps0 - c1.p));
-            const T r_up = phys::limiter<LIM>(Den(c1.ua - gus1 + T(1e-6)).quo(c2.ua - gus2));
+            const T r_up = phys::limiter<LIM>(Den(c1.ua - gus1 + T(1e-6)).quo_t(c2.ua - gus2));
             const T r_pp = phys::limiter<LIM>(Den(c1.p - gps1 + T(1e-6)).quo(c2.p - gps2));
             const T dm_l = c2.rho * dx;
             const T dm_r = c1.rho * dx;
@@ -215,13 +215,13 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
         const T dX = lo.dxl.b;
         const T u = Y_AXIS ? lo.ut : lo.ua, v = Y_AXIS ? lo.ua : lo.ut;   // reference's (u, v)
         const T t_rho  = d_dx.quo(dX * lo.rho        - (a[P0][0] - a[P1][0]));
-        const T t_urho = d_dx.quo(dX * lo.rho * u    - (a[P0][1] - a[P1][1]));
-        const T t_vrho = d_dx.quo(dX * lo.rho * v    - (a[P0][2] - a[P1][2]));
+        const T t_urho = d_dx.quo_t(dX * lo.rho * u    - (a[P0][1] - a[P1][1]));
+        const T t_vrho = d_dx.quo_t(dX * lo.rho * v    - (a[P0][2] - a[P1][2]));
         const T t_Erho = d_dx.quo(dX * lo.rho * lo.E - (a[P0][3] - a[P1][3]));
         Out4<T> o;
         o.rho = t_rho;
         const Den d_rho(t_rho);
-        const T un = d_rho.quo(t_urho), vn = d_rho.quo(t_vrho);
+        const T un = d_rho.quo_t(t_urho), vn = d_rho.quo_t(t_vrho);
         o.ua = Y_AXIS ? vn : un;
         o.ut = Y_AXIS ? un : vn;
         o.E = d_rho.quo(t_Erho);

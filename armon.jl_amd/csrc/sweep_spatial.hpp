@@ -136,7 +136,7 @@ struct SpatialSweep {
         for (int k = 0; k < K; k++) {
             const T rc_l = rcL[k], rc_r = rc[k];
             const Den d(rc_l + rc_r);
-            gus.v[k] = d.quo(rc_l * uL[k] + rc_r * ua[k] + (pL[k] - p[k]));
+            gus.v[k] = d.quo_t(rc_l * uL[k] + rc_r * ua[k] + (pL[k] - p[k]));
             gps.v[k] = d.quo(rc_r * pL[k] + rc_l * p[k] + rc_l * rc_r * (uL[k] - ua[k]));
         }
         S_ fus, fps;
@@ -146,9 +146,9 @@ struct SpatialSweep {
             const Sh gusL = left_of(gus), gpsL = left_of(gps), gusR = right_of(gus), gpsR = right_of(gps);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const T r_um = phys::limiter<LIM>(Den(gus[k] - uL[k] + T(1e-6)).quo(gusR[k] - ua[k]));
+                const T r_um = phys::limiter<LIM>(Den(gus[k] - uL[k] + T(1e-6)).quo_t(gusR[k] - ua[k]));
                 const T r_pm = phys::limiter<LIM>(Den(gps[k] - pL[k] + T(1e-6)).quo(gpsR[k] - p[k]));
-                const T r_up = phys::limiter<LIM>(Den(ua[k] - gus[k] + T(1e-6)).quo(uL[k] - gusL[k]));
+                const T r_up = phys::limiter<LIM>(Den(ua[k] - gus[k] + T(1e-6)).quo_t(uL[k] - gusL[k]));
                 const T r_pp = phys::limiter<LIM>(Den(p[k] - gps[k] + T(1e-6)).quo(pL[k] - gpsL[k]));
                 const T dm_l = rhoL[k] * dx;
                 const T dm_r = rho[k] * dx;
@@ -222,13 +222,13 @@ struct SpatialSweep {
         for (int k = 0; k < K; k++) {
             const T dX = dxl[k];
             const T t_rho  = d_dx.quo(dX * l_rho[k]           - (a0R[k] - a0[k]));
-            const T t_urho = d_dx.quo(dX * l_rho[k] * l_ua[k] - (a1R[k] - a1[k]));
-            const T t_vrho = d_dx.quo(dX * l_rho[k] * ut[k]   - (a2R[k] - a2[k]));
+            const T t_urho = d_dx.quo_t(dX * l_rho[k] * l_ua[k] - (a1R[k] - a1[k]));
+            const T t_vrho = d_dx.quo_t(dX * l_rho[k] * ut[k]   - (a2R[k] - a2[k]));
             const T t_Erho = d_dx.quo(dX * l_rho[k] * l_E[k]  - (a3R[k] - a3[k]));
             const Den d_rho(t_rho);
             o_rho.v[k] = t_rho;
-            o_u.v[k] = d_rho.quo(t_urho);
-            o_v.v[k] = d_rho.quo(t_vrho);
+            o_u.v[k] = d_rho.quo_t(t_urho);
+            o_v.v[k] = d_rho.quo_t(t_vrho);
             o_E.v[k] = d_rho.quo(t_Erho);
         }
     }
