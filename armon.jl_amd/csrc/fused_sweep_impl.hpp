@@ -1468,9 +1468,12 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     int64_t n_blocks = 0;
     int rc;
 #ifdef ARMON_ONLY_HEADLINE   // variant builds for A/B timing (tools/build_variant.sh): one instantiation, seconds to compile
+#ifndef ARMON_ONLY_EOS
+#define ARMON_ONLY_EOS ARMON_EOS_PERFECT_GAS       // -DARMON_ONLY_EOS=ARMON_EOS_BIZARRIUM: the one instantiation is config 5's
+#endif
     ARMON_REQUIRE(d->scheme == ARMON_SCHEME_GAD && d->limiter == ARMON_LIMITER_MINMOD && d->projection == ARMON_PROJECTION_EULER_2ND &&
-                  d->eos == ARMON_EOS_PERFECT_GAS && d->x_kernel == 0, "headline-only variant build");
-    rc = dispatch_exact<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD, ARMON_PROJECTION_EULER_2ND, ARMON_EOS_PERFECT_GAS>(ctx, a, d->axis, exact, track, &n_blocks);
+                  d->eos == ARMON_ONLY_EOS && d->x_kernel == 0, "headline-only variant build");
+    rc = dispatch_exact<ARMON_SCHEME_GAD, ARMON_LIMITER_MINMOD, ARMON_PROJECTION_EULER_2ND, ARMON_ONLY_EOS>(ctx, a, d->axis, exact, track, &n_blocks);
     if (rc != ARMON_OK || !track) return rc;
     return fold_dt_launch(ctx, a.partials, n_blocks, (real)d->cfl_dx, (real)d->cfl_dy, d->dt_cfl_out, d->dt_accumulate, d->dt_state);
 #else
