@@ -83,6 +83,7 @@ struct sweep_args {
     int32_t y_sx = 0;              // Y sweep: rows are stored in sector-aligned windows handed over through LDS (see k_sweep_y)
     armon_dt_state* st = nullptr;   // device-resident time step (graph replay): dt is then a factor of st->current_dt
     real dt, dx, gamma;
+    real inv_dx, dt_dx;            // 1 / dx and dt / dx in the run's precision (host; sweep_begin redoes dt / dx under a device-resident dt)
     real fa_low, ft_low, fa_high, ft_high;   // BC factors: axial / transverse velocity
     const real *rho_in, *ua_in, *ut_in, *E_in;    // ua = velocity along the sweep axis
     real *rho_out, *ua_out, *ut_out, *E_out;
@@ -119,9 +120,13 @@ __device__ __forceinline__ int64_t bc_source(const sweep_args& a, int64_t n, int
 __device__ __forceinline__ bool sweep_begin(sweep_args& a)
 {
     if (a.st) {
-        if (a.st->done) return false;
-        a.dt = (real)a.st->current_dt * a.dt;
-        if (!a.st->emit_p) a.emit &= ~1;
+        // nothing writes the state machine while a sweep runs (it steps in the fold kernel that follows), so it is read
+        // through the constant address space: scalar loads whatever the compiler can prove about the rest of the kernel
+        const auto* st = (const __attribute__((address_space(4))) armon_dt_state*)a.st;
+        if (st->done) return false;
+        a.dt = (real)st->current_dt * a.dt;
+        a.dt_dx = a.dt / a.dx;
+        if (!st->emit_p) a.emit &= ~1;
     }
     return true;
 }
@@ -282,6 +287,9 @@ constexpr int kYSxBlock = 512;     // lanes per workgroup of the Y march with th
 #ifndef ARMON_Y_PF
 #define ARMON_Y_PF 4             // rows prefetched ahead of the march (≤ 5: the cell ring has 8 slots)
 #endif
+#ifndef ARMON_Y_PRIO
+#define ARMON_Y_PRIO 0           // > 0: issue priority of a step's loads (s_setprio around them)
+#endif
 #ifndef ARMON_Y_WAVES
 #define ARMON_Y_WAVES 2          // minimum waves per SIMD the Y march is compiled for (register budget)
 #endif
@@ -314,7 +322,7 @@ k_sweep_y(sweep_args a)
     const rsrc_t w_rho = make_rsrc(a.rho_out + out_base), w_ua = make_rsrc(a.ua_out + out_base);
     const rsrc_t w_ut = make_rsrc(a.ut_out + out_base), w_E = make_rsrc(a.E_out + out_base);
 
-    PIPE pipe(a.dt, a.dx, a.gamma);
+    PIPE pipe(a.dt, a.dx, a.gamma, a.inv_dx, a.dt_dx);
     cfl_track cfl;
 
     int lj = jb;                     // next row to load and its offset from the run's first row
@@ -372,7 +380,13 @@ k_sweep_y(sweep_args a)
     auto step = [&](auto ph, auto checked, int j) {
         constexpr int PH8 = decltype(ph)::value;
         constexpr bool CHECKED = decltype(checked)::value;
+#if ARMON_Y_PRIO
+        __builtin_amdgcn_s_setprio(ARMON_Y_PRIO);            // the row's loads go out ahead of the other wave's arithmetic
+#endif
         load(integral_constant<int, PH8 + PF>{}, checked);   // row j + PF → slot (j + PF) mod 8
+#if ARMON_Y_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         real p, c, c_lag;
 #ifdef ARMON_PROBE_NOCOMPUTE   // calibration build: same loads/stores, no arithmetic (tools/build_variant.sh)
         p = c = c_lag = 0;
@@ -478,7 +492,7 @@ k_sweep_y2(sweep_args a)
     // the two columns of a lane are ONE pipeline on 2-vectors: packed v_pk_* arithmetic (sweep_pipeline.hpp, float2v)
     using V = fused::fast::float2v;
     using PIPEV = fused::PipeFast<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, V>;
-    PIPEV pipe(a.dt, a.dx, a.gamma);
+    PIPEV pipe(a.dt, a.dx, a.gamma, a.inv_dx, a.dt_dx);
     cfl_track cfl;
 
     int lj = jb;                     // next row to load and its offset from the run's first row
@@ -610,6 +624,14 @@ k_sweep_y2(sweep_args a)
 #define ARMON_XS_ROWS 4          // rows (= waves) per workgroup of the X sweep (tuning macro)
 #endif
 constexpr int kXSRows = ARMON_XS_ROWS;
+// ARMON_X_PRIO > 0: a new wave runs its prologue and issues its strip's loads at that priority (s_setprio), ahead of the
+// arithmetic of the older waves of its SIMD, and drops to 0 for its own arithmetic: with four waves per SIMD and ~600 vector
+// instructions per strip, a newcomer otherwise waits its turn behind three compute phases before anything of its own is in
+// flight. Bizarrium (the longest compute phase) 2.91 -> 2.82 ms at 16384², the copy's rate; perfect gas, already at that
+// rate, unchanged (profiles/r04_ab_x_prologue.txt).
+#ifndef ARMON_X_PRIO
+#define ARMON_X_PRIO 3
+#endif
 // One strip per wave (SINGLE): load, sweep, store, exit — no second register set for a prefetched strip, 104-119 VGPRs, 4
 // waves per SIMD; the other waves of the SIMD hide the load. Rounds 1-2 ran TWO strips per wave with the second one's 32
 // input registers prefetched during the first (166-184 VGPRs, 2-3 waves per SIMD): A/B in one process
@@ -678,7 +700,7 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
         vec_ok = (K == 2);
     }
 
-    SW sw{a.dt, a.dx, a.gamma};
+    SW sw{a.dt, a.dx, a.gamma, a.inv_dx, a.dt_dx};
     cfl_track cfl;
     // Strip origins are aligned so that a strip's stores start on a 64-B sector of the ghosted row (for the
     // usual STRIDE = 120 = 15 sectors); the first strip of a row is then a short one (stores masked below o_lo).
@@ -772,10 +794,16 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     if (SINGLE) {
         if (row_ok && strip_exists(0)) {
             load_strip(std::integral_constant<int, 0>{}, 0);
+#if ARMON_X_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             do_strip(std::integral_constant<int, 0>{}, 0);
         }
     } else if (row_ok && strip_exists(0)) {
         load_strip(std::integral_constant<int, 0>{}, 0);
+#if ARMON_X_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         for (int it = 0; strip_exists(it); it += 2) {
             do_strip(std::integral_constant<int, 0>{}, it);
             if (!strip_exists(it + 1)) break;
@@ -798,10 +826,32 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
 #ifndef ARMON_XS_WAVES
 #define ARMON_XS_WAVES 1         // minimum waves per SIMD the X sweep is compiled for (tuning macro; 3 = cap at 168 VGPRs)
 #endif
+// hipcc loads a kernel argument from the kernarg segment in the basic block that first uses it: this kernel's prologue then
+// holds FOUR dependent scalar-load round trips (st, the geometry, niter, the pointers) before its first vector load — and a
+// wave of the one-strip form lives for one strip, so that latency is paid per strip with nothing of the wave's own in
+// flight. Naming every field the hot path reads in one empty asm statement at entry makes the compiler issue all the
+// s_loads together, behind ONE wait (ARMON_X_PRELOAD=0: the lazy form, for A/B).
+#ifndef ARMON_X_PRELOAD
+#define ARMON_X_PRELOAD 1
+#endif
+__device__ __forceinline__ void preload_x_args(const sweep_args& a, int niter)
+{
+#if ARMON_X_PRELOAD
+    asm volatile("" ::"s"(a.nx), "s"(a.ny), "s"(a.row_len), "s"(a.g), "s"(a.bc_low), "s"(a.bc_high), "s"(a.emit), "s"(a.o_lo),
+                 "s"(a.o_hi), "s"(a.x_first), "s"(a.xcd_remap), "s"(a.x_wg_along_x), "s"(a.x_row_align), "s"(niter));
+    asm volatile("" ::"s"(a.dt), "s"(a.dx), "s"(a.gamma), "s"(a.inv_dx), "s"(a.dt_dx), "s"(a.rho_in), "s"(a.ua_in), "s"(a.ut_in),
+                 "s"(a.E_in), "s"(a.rho_out), "s"(a.ua_out), "s"(a.ut_out), "s"(a.E_out));
+#endif
+}
+
 template <int SCHEME, int LIM, int PROJ, int EOS, bool EXACT, int K, bool TRACK, bool SINGLE = true, int ROW = 0>
 __global__ void __launch_bounds__(64 * kXSRows, ARMON_XS_WAVES)
 k_sweep_x_dpp(sweep_args a, int niter)
 {
+#if ARMON_X_PRIO
+    __builtin_amdgcn_s_setprio(ARMON_X_PRIO);     // until the strip's loads are issued (sweep_x_dpp_body lowers it again)
+#endif
+    preload_x_args(a, niter);
     if (!sweep_begin(a)) return;
     sweep_x_dpp_body<SCHEME, LIM, PROJ, EOS, EXACT, K, TRACK, SINGLE, ROW>(a, niter);
 }
@@ -855,7 +905,7 @@ k_cycle_xy(sweep_args a, real dt_y, real dx_y)
     const rsrc_t w_rho = make_rsrc(a.rho_out + out_base), w_u = make_rsrc(a.ua_out + out_base);
     const rsrc_t w_v = make_rsrc(a.ut_out + out_base), w_E = make_rsrc(a.E_out + out_base);
 
-    SW sw{a.dt, a.dx, a.gamma};
+    SW sw{a.dt, a.dx, a.gamma, a.inv_dx, a.dt_dx};
     PIPE pipe(dt_y, dx_y, a.gamma);
     cfl_track cfl;
     // Y boundary factors act on the X-swept state exactly as the reference's mirror does between its two sweeps
@@ -944,7 +994,7 @@ __device__ __forceinline__ void pc_producer(const sweep_args& a, const pc_geom& 
     const int64_t nx = a.nx, w0 = gm.w0;
     const int ny = (int)a.ny, g = a.g, jb = gm.jb, T = gm.T;
         // ---- producer: X stage of row jb + t into ring slot t & 1
-        SW sw{a.dt, a.dx, a.gamma};
+        SW sw{a.dt, a.dx, a.gamma, a.inv_dx, a.dt_dx};
         St buf[2][4];
         const int64_t cb = w0 - HALO;                                    // first cell of the strip
         const int64_t j0 = cb + 2 * (int64_t)lane;                       // this lane's first cell
@@ -1385,6 +1435,8 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     a.dt = (real)d->dt;
     a.dx = (real)d->dx;
     a.gamma = (real)d->gamma;
+    a.inv_dx = real(1) / a.dx;        // IEEE quotients: the bits the kernels' own divisions gave until round 4
+    a.dt_dx = a.dt / a.dx;
     const bool X = d->axis == ARMON_AXIS_X;
     a.fa_low = (real)(X ? d->u_factor_low : d->v_factor_low);
     a.ft_low = (real)(X ? d->v_factor_low : d->u_factor_low);
@@ -1706,6 +1758,8 @@ extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const A
     a.dt = (real)x->dt;
     a.dx = (real)x->dx;
     a.gamma = (real)x->gamma;
+    a.inv_dx = real(1) / a.dx;
+    a.dt_dx = a.dt / a.dx;
     a.fa_low = (real)x->u_factor_low;     // X sweep: axial = u, transverse = v
     a.ft_low = (real)x->v_factor_low;
     a.fa_high = (real)x->u_factor_high;

@@ -66,6 +66,8 @@ struct Pipe : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     T a[2][4];             // advection fluxes at interfaces na / na-1
     T csr[4];              // ring: sound speed of cells j .. j-3 (dt/CFL tracking only)
 
+    // (the two quotients the tuned pipeline takes from its caller are not used here: the exact flavour prepares denominators)
+    __device__ __forceinline__ Pipe(T dt_, T dx_, T gamma_, T /*inv_dx*/, T /*dt_dx*/) : Pipe(dt_, dx_, gamma_) {}
     __device__ __forceinline__ Pipe(T dt_, T dx_, T gamma_) : dt(dt_), dx(dx_), gamma(gamma_), d_dx(dx_)
     {
         dsum[0] = dsum[1] = Den(dx_ + dx_);
@@ -363,10 +365,12 @@ struct PipeFast : PipeTraits<SCHEME, LIM, PROJ, EOS> {
     T a[2][4];
     T csr[4];
 
-    __device__ __forceinline__ PipeFast(Sc dt_, Sc dx_, Sc gamma_) : dt(dt_), dx(dx_), gamma(gamma_)
+    __device__ __forceinline__ PipeFast(Sc dt_, Sc dx_, Sc gamma_) : PipeFast(dt_, dx_, gamma_, Sc(1.) / dx_, dt_ / dx_) {}
+    // inv_dx_ = 1 / dx, dt_dx_ = dt / dx as IEEE quotients in the run's precision (the host forms them once per launch)
+    __device__ __forceinline__ PipeFast(Sc dt_, Sc dx_, Sc gamma_, Sc inv_dx_, Sc dt_dx_) : dt(dt_), dx(dx_), gamma(gamma_)
     {
-        inv_dx = Sc(1.) / dx_;
-        dt_dx = dt_ / dx_;
+        inv_dx = inv_dx_;
+        dt_dx = dt_dx_;
         gm1 = gamma_ - Sc(1.);
         ggm1 = gamma_ * (gamma_ - Sc(1.));
 #pragma unroll

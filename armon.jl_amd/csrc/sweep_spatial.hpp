@@ -104,6 +104,10 @@ struct SpatialSweep {
     static __device__ __forceinline__ Sh right_of(const S_& s) { return fused::right_of<ROW, K, T>(s); }
 
     T dt, dx, gamma;
+    // 1 / dx and dt / dx, formed by the caller (the host, in the run's precision; armon_hip_sweep): a wave lives for one
+    // strip, and the two IEEE divisions (two v_rcp_f64 at 4x the issue cost of an FMA + their expansions, ~40 FMA slots of
+    // a strip's ~600) were per-wave work. Tuned arithmetic only; the exact flavour prepares its own denominators.
+    T inv_dx, dt_dx;
 
     __device__ __forceinline__ void run(const S_& rho, const S_& u, const S_& v, const S_& E,
                                         S_& o_rho, S_& o_u, S_& o_v, S_& o_E, S_& p, S_& cs) const
@@ -238,7 +242,7 @@ struct SpatialSweep {
                                              S_& o_rho, S_& o_u, S_& o_v, S_& o_E, S_& p, S_& cs) const
     {
         using namespace fast;
-        const T inv_dx = T(1.) / dx, dt_dx = dt / dx, gm1 = gamma - T(1.), ggm1 = gamma * (gamma - T(1.));
+        const T gm1 = gamma - T(1.), ggm1 = gamma * (gamma - T(1.));
         S_ rc;
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -306,13 +310,20 @@ struct SpatialSweep {
         const Sh rL = left_of(l_rho), quL = left_of(q_ua), qvL = left_of(q_ut), qEL = left_of(q_E);
         if (W == 1) {
             const Sh rR = right_of(l_rho), quR = right_of(q_ua), qvR = right_of(q_ut), qER = right_of(q_E);
-            const Sh dxlL = left_of(dxl), dxlR = right_of(dxl);
+            // r₋ = 2Δx / (Δx + Δx₋), r₊ = 2Δx / (Δx + Δx₊): a cell's Δx + Δx₊ is its right neighbour's Δx₋ + Δx (the same
+            // bits: IEEE addition commutes), so every cell inverts ONE sum and takes the other reciprocal from its
+            // neighbour (one shift instead of a second v_rcp_f64, which issues at a quarter of an FMA's rate)
+            const Sh dxlL = left_of(dxl);
+            S_ isum;
+#pragma unroll
+            for (int k = 0; k < K; k++) isum.v[k] = rcp1(dxl[k] + dxlL[k]);
+            const Sh isumR = right_of(isum);
             S_ s0, s1, s2, s3;
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const T two_dxl = T(2.) * dxl[k];
-                const T r_m = two_dxl * rcp1(dxl[k] + dxlL[k]);
-                const T r_p = two_dxl * rcp1(dxl[k] + dxlR[k]);
+                const T r_m = two_dxl * isum[k];
+                const T r_p = two_dxl * isumR[k];
                 s0.v[k] = minmod(r_p * (rR[k] - l_rho[k]), r_m * (l_rho[k] - rL[k]));
                 s1.v[k] = minmod(r_p * (quR[k] - q_ua[k]), r_m * (q_ua[k] - quL[k]));
                 s2.v[k] = minmod(r_p * (qvR[k] - q_ut[k]), r_m * (q_ut[k] - qvL[k]));

@@ -61,6 +61,10 @@ OP32(rcp32, "v_rcp_f32 %0, %0")
 OP32(dpp, "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
 OP32(dpprow, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
 OP32(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+OP32(cndmask_s, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+OP32(cndmask_c, "v_cndmask_b32_e64 %0, %0, 1.0, vcc")
+OP32(cndmask_ab, "v_cndmask_b32_e32 %0, %1, %0, vcc")
+OP32(cmp_cnd, "v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
 OP1(cmp, "v_cmp_gt_f64 vcc, %0, %1")
 OP1(pkfma, "v_pk_fma_f32 %0, %0, %1, %1")
 OP1(pkmul, "v_pk_mul_f32 %0, %0, %1")
@@ -111,7 +115,7 @@ int main()
     printf("device %s, %d CUs, clockRate %.0f MHz (the instruction counts below assume the clock stays there)\n", prop.gcnArchName,
            prop.multiProcessorCount, mhz);
 #define M(name) measure(#name, k_##name, out, cyc, mhz);
-    M(fma) M(fma) M(mul) M(add) M(max) M(min) M(rcp) M(rsq) M(sqrt) M(mov64) M(fma32) M(rcp32) M(dpp) M(dpprow) M(cndmask) M(cmp)
+    M(fma) M(fma) M(mul) M(add) M(max) M(min) M(rcp) M(rsq) M(sqrt) M(mov64) M(fma32) M(rcp32) M(dpp) M(dpprow) M(cndmask) M(cndmask_s) M(cndmask_c) M(cndmask_ab) M(cmp_cnd) M(cmp)
     M(pkfma) M(pkmul) M(div_scale) M(div_fmas) M(div_fixup) M(frexp) M(ldexp)
     return 0;
 }
