@@ -96,7 +96,7 @@ def measure_traffic(args):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not found"
-    child = [os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--cells", str(args.n),
+    child = [os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-measure-traffic", "--cells", str(args.n),
              "--test", args.test, "--scheme", args.scheme]
     child += ["--staged"] if args.staged else []
     child += ["--exact"] if args.exact else []
@@ -160,96 +160,12 @@ def cpu_baseline(test, scheme, target_seconds=12.0):
                       f"({run.solve_seconds:.1f} s), oracle/armon_oracle.c -O3 -march=native -ffp-contract=off OpenMP (oracle/Makefile)"}
 
 
-def main():
-    # The contract is ONE JSON line on stdout. RCCL and gloo print banners on fd 1 while they initialise: send
-    # everything written to fd 1 during the run to stderr and keep the real stdout for that line alone.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cells", type=int, default=16384, dest="n", help="cells per axis PER GPU (weak scaling)")
-    ap.add_argument("--test", default="Sod")
-    ap.add_argument("--scheme", default="GAD")
-    ap.add_argument("--staged", action="store_true", help="5 staged kernels per sweep instead of the fused one")
-    ap.add_argument("--exact", action="store_true",
-                    help="IEEE division/sqrt, no contraction (bit-identical to the CPU oracle) instead of the "
-                         "default tuned arithmetic (shared 1-ulp reciprocals + FMA, within the reference's tolerance)")
-    ap.add_argument("--fast", action="store_true", help="(default) tuned arithmetic; kept for compatibility")
-    ap.add_argument("--f32", action="store_true", help="Float32 data_type (the _f32 entry points) instead of the fp64 headline")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--measure-traffic", action="store_true",
-                    help="roofline.traffic from two child rocprofv3 --pmc passes of this command (adds ≈1 min) instead "
-                         "of the committed passes replayed from profiles/")
-    ap.add_argument("--global", dest="global_grid", default=None, metavar="NXxNY",
-                    help="GLOBAL grid, split over the process grid (tiles = N÷P, remainder on the last tile, ref "
-                         "src/parameters.jl:673-697); default: --cells² per GPU (weak scaling)")
-    ap.add_argument("--grid", default=None, metavar="PXxPY", help="process grid (default: 1x1, 2x1, 2x2, 4x2 for 1, 2, 4, 8 ranks)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: the global grid stays --cells² (or --global) whatever the number of GPUs")
-    ap.add_argument("--require-native", action="store_true",
-                    help="N > 1: exit with status 3 (after printing the line) when the halos do not travel through the "
-                         "library's own RCCL exchange, i.e. when config.halo_exchange_downgraded is true")
-    ap.add_argument("--config", type=int, choices=(2, 3, 4, 5), default=None,
-                    help="BASELINE.json configs[N-1]: 2 = Sod 8192² Godunov, 3 = Sedov 16384², "
-                         "4 = Sod 32768x16384 on 2x2, 5 = Bizarrium 32768² on 4x2")
-    args = ap.parse_args()
-    if args.config == 2:
-        args.test, args.scheme, args.n = "Sod", "Godunov", 8192
-    elif args.config == 3:
-        args.test, args.n = "Sedov", 16384
-    elif args.config == 4:
-        args.test, args.global_grid, args.grid = "Sod", "32768x16384", "2x2"
-    elif args.config == 5:
-        args.test, args.global_grid, args.grid = "Bizarrium", "32768x32768", "4x2"
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-
-    live_traffic = None
-    if args.measure_traffic and world == 1:              # child processes first: this one has not touched the GPU yet
-        live_traffic = measure_traffic(args)
-
-    dist = None
-    if world > 1 or os.environ.get("ARMON_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise RCCL init/all-reduce with one rank
-        import torch
-        import torch.distributed as dist
-        if world == 1:                 # ARMON_BENCH_FORCE_DIST without a launcher: a one-rank rendezvous on this host
-            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
-                os.environ.setdefault(k, v)
-        # Rehearsal knob (one-GPU box): ARMON_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo with host
-        # staging, to exercise this code path; real runs use one GPU per rank over RCCL.
-        rehearsal = os.environ.get("ARMON_BENCH_REHEARSAL") == "1"
-        if rehearsal:
-            local_rank = 0
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+def run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live_traffic=None, primary=True):
+    """Build the grid of one workload on this rank's GPU, choose the halo transport, warm up, time args.steps cycles
+    (barrier + device synchronisation on both sides, maximum over ranks) and return what the line reports about it.
+    ``primary``: the workload `value` is quoted on (the secondary one of an N > 1 run skips the copy ceiling and traffic)."""
     import armon_amd
-    from armon_amd.parameters import proc_grid_for
     from armon_amd.solver import BlockGrid, init_test, solver_cycle
-
-    P = tuple(int(v) for v in args.grid.lower().split("x")) if args.grid else proc_grid_for(world)   # (px, py), e.g. 8 → (4, 2)
-    if len(P) != 2 or P[0] * P[1] != world:
-        sys.exit(f"--grid {args.grid}: {world} rank(s) cannot form that process grid")
-    if args.global_grid:
-        N_global = tuple(int(v) for v in args.global_grid.lower().split("x"))
-        scaling = "strong"                                    # a named global grid: total work is fixed
-    elif args.strong:
-        N_global = (args.n, args.n)                           # strong scaling: the same n×n grid whatever the GPU count
-        scaling = "strong"
-    else:
-        N_global = (args.n * P[0], args.n * P[1])             # weak scaling: n×n cells per GPU
-        scaling = "weak"
     params = armon_amd.ArmonParameters(
         test=args.test, N=N_global, scheme=args.scheme, riemann_limiter="minmod", projection="euler_2nd",
         axis_splitting="Sequential", nghost=4, maxtime=1e9, maxcycle=10 ** 9, silent=5,
@@ -389,7 +305,7 @@ def main():
 
     # Practical ceiling on THIS device: the same bytes (4 arrays read + 4 written) as a plain copy, no arithmetic.
     copy_gbps = None
-    if grid.alt is not None:
+    if grid.alt is not None and primary:
         from armon_amd.solver import STATE_VARS
         src, dst = [grid.data[f] for f in STATE_VARS], [grid.alt[f] for f in STATE_VARS]
         nb = src[0].nbytes & ~15
@@ -420,7 +336,7 @@ def main():
     mean_ms = sum(all_ms) / max(sweeps_timed, 1)
     bpc = B_PER_CELL[dominant[0]] // (2 if args.f32 else 1)
     achieved = bpc * cells_local / (mean_ms * 1e-3) / 1e9 if all_ms else 0.0
-    traffic, traffic_source = pmc_traffic(args, world, N_global)
+    traffic, traffic_source = pmc_traffic(args, world, N_global) if primary else (None, None)
     if live_traffic is not None:
         if live_traffic[0] is not None:
             traffic, traffic_source = live_traffic
@@ -435,6 +351,125 @@ def main():
     if copy_gbps:
         roofline["stream_copy_GBps_this_device"] = round(copy_gbps, 1)     # measured right after the timed region
         roofline["frac_of_stream_copy"] = round(achieved / copy_gbps, 4)
+    res = dict(value=value, elapsed=elapsed, roofline=roofline, self_check=self_check, placement=placement,
+               halo_mode=halo_mode, halo_downgraded=halo_downgraded, halo_errors=halo_errors, tile=tuple(params.N),
+               cells_local=cells_local, cells_total=cells_total, sweeps=sweeps, device=params.device.name)
+    # release this workload's communicators and vectors before the next one is built
+    if dist is not None:
+        for comm in {id(c): c for c in (grid.comm, locals().get("native_comm"), locals().get("torch_comm")) if c is not None}.values():
+            if hasattr(comm, "close"):
+                comm.close()                   # the library's RCCL communicators, before the launcher's
+    params.kernel_callbacks.remove(timer)
+    del grid
+    import gc
+    gc.collect()
+    return res
+
+
+
+def main():
+    # The contract is ONE JSON line on stdout. RCCL and gloo print banners on fd 1 while they initialise: send
+    # everything written to fd 1 during the run to stderr and keep the real stdout for that line alone.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cells", type=int, default=16384, dest="n", help="cells per axis PER GPU (weak scaling)")
+    ap.add_argument("--test", default="Sod")
+    ap.add_argument("--scheme", default="GAD")
+    ap.add_argument("--staged", action="store_true", help="5 staged kernels per sweep instead of the fused one")
+    ap.add_argument("--exact", action="store_true",
+                    help="IEEE division/sqrt, no contraction (bit-identical to the CPU oracle) instead of the "
+                         "default tuned arithmetic (shared 1-ulp reciprocals + FMA, within the reference's tolerance)")
+    ap.add_argument("--fast", action="store_true", help="(default) tuned arithmetic; kept for compatibility")
+    ap.add_argument("--f32", action="store_true", help="Float32 data_type (the _f32 entry points) instead of the fp64 headline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="(default at --gpus 1 when rocprofv3 is on PATH) roofline.traffic from two child rocprofv3 --pmc "
+                         "passes of this command (adds ≈1 min)")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="roofline.traffic replayed from the committed passes under profiles/ instead of measured for this line")
+    ap.add_argument("--global", dest="global_grid", default=None, metavar="NXxNY",
+                    help="GLOBAL grid, split over the process grid (tiles = N÷P, remainder on the last tile, ref "
+                         "src/parameters.jl:673-697); default: --cells² per GPU (weak scaling)")
+    ap.add_argument("--grid", default=None, metavar="PXxPY", help="process grid (default: 1x1, 2x1, 2x2, 4x2 for 1, 2, 4, 8 ranks)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the global grid stays --cells² (or --global) whatever the number of GPUs")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1, default workload: skip the strong-scaling workload timed after the weak one")
+    ap.add_argument("--strong-timeout", type=float, default=300.,
+                    help="seconds the strong-scaling workload may take before the weak line is printed without it")
+    ap.add_argument("--require-native", action="store_true",
+                    help="N > 1: exit with status 3 (after printing the line) when the halos do not travel through the "
+                         "library's own RCCL exchange, i.e. when config.halo_exchange_downgraded is true")
+    ap.add_argument("--config", type=int, choices=(2, 3, 4, 5), default=None,
+                    help="BASELINE.json configs[N-1]: 2 = Sod 8192² Godunov, 3 = Sedov 16384², "
+                         "4 = Sod 32768x16384 on 2x2, 5 = Bizarrium 32768² on 4x2")
+    args = ap.parse_args()
+    if args.config == 2:
+        args.test, args.scheme, args.n = "Sod", "Godunov", 8192
+    elif args.config == 3:
+        args.test, args.n = "Sedov", 16384
+    elif args.config == 4:
+        args.test, args.global_grid, args.grid = "Sod", "32768x16384", "2x2"
+    elif args.config == 5:
+        args.test, args.global_grid, args.grid = "Bizarrium", "32768x32768", "4x2"
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    from armon_amd.parameters import proc_grid_for
+    P = tuple(int(v) for v in args.grid.lower().split("x")) if args.grid else proc_grid_for(world)   # (px, py), e.g. 8 → (4, 2)
+    if len(P) != 2 or P[0] * P[1] != world:
+        sys.exit(f"--grid {args.grid}: {world} rank(s) cannot form that process grid")
+
+    # roofline.traffic is MEASURED for the line by default (N = 1): two child passes of this command under rocprofv3 --pmc,
+    # before this process touches the GPU. Not from inside a profiler (tools/profile_*.sh run this file under rocprofv3:
+    # a profiler in a profiled child is refused on this pool), not in the children themselves; the committed passes are
+    # then replayed, and the line says which it was (roofline.traffic_source).
+    live_traffic = None
+    under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+    if world == 1 and not args.no_measure_traffic and os.environ.get("ARMON_BENCH_FORCE_DIST") != "1":
+        live_traffic = (None, "running under a profiler") if under_profiler else measure_traffic(args)
+
+    dist = None
+    if world > 1 or os.environ.get("ARMON_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise RCCL init/all-reduce with one rank
+        import torch
+        import torch.distributed as dist
+        if world == 1:                 # ARMON_BENCH_FORCE_DIST without a launcher: a one-rank rendezvous on this host
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
+        # Rehearsal knob (one-GPU box): ARMON_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo with host
+        # staging, to exercise this code path; real runs use one GPU per rank over RCCL.
+        rehearsal = os.environ.get("ARMON_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.global_grid:
+        N_global = tuple(int(v) for v in args.global_grid.lower().split("x"))
+        scaling = "strong"                                    # a named global grid: total work is fixed
+    elif args.strong:
+        N_global = (args.n, args.n)                           # strong scaling: the same n×n grid whatever the GPU count
+        scaling = "strong"
+    else:
+        N_global = (args.n * P[0], args.n * P[1])             # weak scaling: n×n cells per GPU
+        scaling = "weak"
+    r = run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live_traffic)
+    value, elapsed, roofline, self_check = r["value"], r["elapsed"], r["roofline"], r["self_check"]
+    halo_mode, halo_downgraded, halo_errors, placement = r["halo_mode"], r["halo_downgraded"], r["halo_errors"], r["placement"]
+    cells_local, cells_total, sweeps, tile = r["cells_local"], r["cells_total"], r["sweeps"], r["tile"]
 
     prec = "fp32" if args.f32 else "fp64"
     out = {
@@ -444,20 +479,59 @@ def main():
         "scaling": "strong" if scaling == "strong" else "weak",
         "vs_baseline": None, "dtype": "f32" if args.f32 else "f64", "data": "synthetic",
         "config": {"workload": f"{args.test} {N_global[0]}x{N_global[1]} {prec}, {args.scheme}+minmod+euler_2nd, "
-                               f"Sequential X,Y splitting, nghost 4, {P[0]}x{P[1]} tiles of {params.N[0]}x{params.N[1]} cells "
+                               f"Sequential X,Y splitting, nghost 4, {P[0]}x{P[1]} tiles of {tile[0]}x{tile[1]} cells "
                                f"({scaling} scaling)",
                    "baseline_config": args.config,
                    "path": "staged (5 kernels/sweep)" if args.staged else "fused sweep",
                    "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local,
-                   "hbm_placement": placement, "device": params.device.name, "halo_exchange": halo_mode,
+                   "hbm_placement": placement, "device": r["device"], "halo_exchange": halo_mode,
                    "halo_exchange_downgraded": halo_downgraded,
                    "halo_exchange_error": "; ".join(halo_errors) if halo_errors else None},
         "hbm_GBps_algorithmic_whole_job": round((32 if args.f32 else 64) * cells_total * sweeps / elapsed / 1e9, 1),
         "roofline": roofline,
         "self_check": self_check,
     }
+    # N > 1 with the default (weak) workload: BASELINE.json's metric is quoted on "16384² Sod, 1/2/4/8", which is the
+    # STRONG curve — the same --cells² grid split over the process grid (tiles by the reference's rule,
+    # ref src/parameters.jl:673-697). It is timed right after the weak workload, in the same processes, and reported
+    # next to `value` (which stays the weak one: `scaling` names it). The weak line is the contract and is complete at
+    # this point: a second workload that raises on some rank, or hangs in a collective because it did, must not cost
+    # it — a watchdog prints the line as it stands and ends the process after --strong-timeout seconds.
+    if world > 1 and scaling == "weak" and not args.no_strong:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["strong"] = {"value": None, "error": f"no result after {args.strong_timeout} s (a rank failed or a collective hung)"}
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(args.strong_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            s2 = run_workload(args, dist, world, rank, local_rank, P, (args.n, args.n), "strong", primary=False)
+            out["strong"] = {
+                "value": round(s2["value"], 1), "unit": "Mcells/s", "ms_per_step": round(s2["elapsed"] / args.steps * 1e3, 4),
+                "workload": f"{args.test} {args.n}x{args.n} split over {P[0]}x{P[1]} tiles of {s2['tile'][0]}x{s2['tile'][1]} cells (strong scaling)",
+                "efficiency_vs_ideal": round(s2["value"] / value, 4),
+                "ideal": "this run's weak-scaling value: every GPU at the rate of a full --cells² tile",
+                "roofline_frac": s2["roofline"]["frac"], "per_kernel_ms": s2["roofline"]["per_kernel_ms"],
+                "halo_exchange": s2["halo_mode"], "halo_exchange_downgraded": s2["halo_downgraded"],
+                "self_check": s2["self_check"]}
+            if s2["halo_downgraded"] and not halo_downgraded:
+                halo_downgraded, halo_mode = True, s2["halo_mode"]
+                halo_errors = halo_errors + [e for e in s2["halo_errors"] if e not in halo_errors]
+                out["config"]["halo_exchange_downgraded"] = True
+                out["config"]["halo_exchange_error"] = "; ".join(halo_errors) if halo_errors else None
+        except Exception as e:
+            out["strong"] = {"value": None, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+            if rank == 0:                 # the other ranks may be inside a collective this one will never join
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        watchdog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.f32:
         try:
             out["cpu_baseline"] = cpu_baseline(args.test, args.scheme)
@@ -468,9 +542,6 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
-        for comm in {id(c): c for c in (grid.comm, locals().get("native_comm")) if c is not None}.values():
-            if hasattr(comm, "close"):
-                comm.close()                   # the library's RCCL communicators, before the launcher's
         dist.destroy_process_group()
     if halo_downgraded:
         print(f"bench.py: HALO EXCHANGE DOWNGRADED on rank {rank}: {halo_mode}; {'; '.join(halo_errors)}", file=sys.stderr)
