@@ -11,12 +11,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libarmon_hip.so")
 # A/B build: the product library + the measured-and-rejected kernel forms (-DARMON_ALT_KERNELS: whole-cycle kernels, LDS X
-# march, one-cell-per-lane DPP sweep) + the exact arithmetic in its strict form (-DARMON_STRICT_SUBNORMAL: quotients that can
-# fall below the normal range take the IEEE expansion, -5 % on the exact sweeps; csrc/physics.hpp). Only the tests and tools
-# that exercise those load it.
+# march, one-cell-per-lane DPP sweep). Only the tests and tools that exercise those load it. (Both libraries carry the exact
+# arithmetic in its strict form since round 4: quotients that can fall below the normal range take the IEEE expansion,
+# csrc/physics.hpp.)
 OUT_ALT = os.path.join(HERE, "libarmon_hip_alt.so")
 ALT_SOURCES = ("fused_sweep_f64.hip", "fused_sweep_f32.hip", "staged_kernels.hip")     # the translation units the defines change
-ALT_FLAGS = ["-DARMON_ALT_KERNELS", "-DARMON_STRICT_SUBNORMAL"]
+ALT_FLAGS = ["-DARMON_ALT_KERNELS"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: the "exact" kernels must evaluate one IEEE op per source op (bit parity with the

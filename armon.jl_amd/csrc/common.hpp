@@ -35,6 +35,9 @@ struct armon_ctx {
     // y_run_length's last answer (it depends on the shape only)
     int64_t seg_nx = -1, seg_ny = -1;
     int seg_lag = -1, seg_cols = -1, seg_value = 0;
+    // graphs captured on this context bake the address of `partials` in: it must not move while one is alive
+    int live_graphs = 0;
+    bool capturing = false;
 };
 
 namespace armon {

@@ -22,6 +22,14 @@ void set_error(const char* fmt, ...)
 int ensure_partials(armon_ctx* ctx, size_t n)
 {
     if (n <= ctx->partials_cap) return ARMON_OK;
+    // A graph captured on this context holds the OLD address in its kernel arguments (and a capture in progress can neither
+    // synchronise nor allocate): growing now would leave it with a dangling pointer. The caller runs the larger launch
+    // once BEFORE capturing, or destroys the graph first (include/armon_hip.h, armon_hip_graph_*).
+    ARMON_REQUIRE(!ctx->capturing, "the reduction scratch would have to grow (%zu -> %zu doubles) inside a stream capture: "
+                  "run this launch once before armon_hip_graph_begin", ctx->partials_cap, n);
+    ARMON_REQUIRE(ctx->live_graphs == 0, "the reduction scratch would have to grow (%zu -> %zu doubles) while %d captured graph(s) of "
+                  "this context point into it: destroy them first, or run the larger launch before capturing",
+                  ctx->partials_cap, n, ctx->live_graphs);
     // Grow only between kernels of the same stream: the old buffer may still be read by queued work.
     ARMON_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->partials) ARMON_HIP_TRY(hipFree(ctx->partials));

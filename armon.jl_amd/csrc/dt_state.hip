@@ -17,6 +17,7 @@ using namespace armon;
 struct armon_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    armon_ctx* ctx = nullptr;        // the context whose scratch the captured kernels point into
 };
 
 namespace {
@@ -58,8 +59,14 @@ int armon_hip_dt_state_step_f32(armon_ctx* ctx, armon_dt_state* st, const float*
 int armon_hip_graph_begin(armon_ctx* ctx)
 {
     ARMON_REQUIRE(ctx, "ctx is NULL");
+    // Capture needs a stream of the library's own: the legacy null stream cannot be captured, and capturing a stream the
+    // caller handed in (armon_hip_init with a stream) would swallow the caller's own work on it.
+    ARMON_REQUIRE(ctx->stream != nullptr && ctx->owns_stream, "graph capture needs a context that owns its stream "
+                  "(armon_hip_init with stream = NULL creates one)");
+    ARMON_REQUIRE(!ctx->capturing, "a capture is already in progress on this context");
     ARMON_HIP_TRY(hipSetDevice(ctx->device));
     ARMON_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
     return ARMON_OK;
 }
 
@@ -68,6 +75,7 @@ int armon_hip_graph_end(armon_ctx* ctx, armon_graph** out)
     ARMON_REQUIRE(ctx && out, "NULL argument");
     *out = nullptr;
     hipGraph_t graph = nullptr;
+    ctx->capturing = false;           // whatever EndCapture returns, the stream is out of capture mode afterwards
     ARMON_HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
     ARMON_REQUIRE(graph, "nothing was captured");
     hipGraphExec_t exec = nullptr;
@@ -79,6 +87,8 @@ int armon_hip_graph_end(armon_ctx* ctx, armon_graph** out)
     armon_graph* g = new armon_graph();
     g->graph = graph;
     g->exec = exec;
+    g->ctx = ctx;
+    ctx->live_graphs++;
     *out = g;
     return ARMON_OK;
 }
@@ -93,6 +103,7 @@ int armon_hip_graph_launch(armon_ctx* ctx, armon_graph* g)
 int armon_hip_graph_destroy(armon_graph* g)
 {
     if (!g) return ARMON_OK;
+    if (g->ctx && g->ctx->live_graphs > 0) g->ctx->live_graphs--;
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;

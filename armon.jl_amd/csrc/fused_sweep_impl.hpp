@@ -1420,6 +1420,10 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     ARMON_REQUIRE(d->x_kernel == 0, "x_kernel form %d is a measured alternative: only libarmon_hip_alt.so (-DARMON_ALT_KERNELS) carries it",
                   d->x_kernel);
 #endif
+    // only the kernels the solver runs read the device-resident time step (sweep_begin): the LDS X march of the A/B build
+    // would take `dt` (then a factor) for the step itself, silently
+    ARMON_REQUIRE(!d->dt_state || d->x_kernel == 0 || d->x_kernel == 3,
+                  "dt_state is not honoured by x_kernel form %d (only the DPP X sweeps and the Y march read it)", d->x_kernel);
     const bool exact = d->exact != 0;
     const bool track = d->dt_cfl_out != nullptr;
     ARMON_REQUIRE(!track || (d->cfl_dx > 0 && d->cfl_dy > 0), "dt_cfl_out needs cfl_dx, cfl_dy > 0");
@@ -1740,6 +1744,7 @@ extern "C" int ARMON_CYCLE_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* x, const A
     ARMON_REQUIRE(x->nx > 0 && x->ny > 0 && x->nx < (1ll << 30) && x->ny < (1ll << 30), "invalid block %lld x %lld", (long long)x->nx, (long long)x->ny);
     ARMON_REQUIRE(x->out_hi == 0 && !x->p_out && !x->c_out && !x->dt_cfl_out, "partial X sweeps / X outputs are not available in the whole-cycle kernel");
     ARMON_REQUIRE(x->x_kernel == 0 || x->x_kernel == 4, "unknown form %d of the whole-cycle kernel", x->x_kernel);
+    ARMON_REQUIRE(!x->dt_state && !y->dt_state, "the whole-cycle kernels do not read a device-resident time step (dt_state)");
     ARMON_REQUIRE(x->rho_in && x->u_in && x->v_in && x->E_in && y->rho_out && y->u_out && y->v_out && y->E_out, "NULL state array");
     ARMON_REQUIRE(x->rho_in != y->rho_out && x->u_in != y->u_out && x->v_in != y->v_out && x->E_in != y->E_out, "in and out arrays must not alias");
     constexpr int lag = 4;

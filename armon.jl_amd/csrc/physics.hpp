@@ -68,14 +68,14 @@ template <> struct Den<double> {
     }
     // a / b where the quotient may fall below the normal range — the velocities of a fluid at rest, their fluxes and slope
     // ratios (Sedov's far field carries 1e-320). There quo()'s remainder step underflows and the result can be one unit of
-    // the subnormal grid (4.9e-324) off an IEEE division: the ONE stated exception to the bit parity of the exact flavour
-    // (1 run in 800 of tests/test_gpu_random_shapes.py). -DARMON_STRICT_SUBNORMAL sends the rare tiny
-    // quotient through the IEEE expansion instead — every bit then, for 5 % of the VALU-bound exact sweeps (seven guarded
-    // quotients per cell); the A/B library is built that way and the random sweep holds it to strict equality.
+    // the subnormal grid (4.9e-324) off an IEEE division (1 run in 800 of tests/test_gpu_random_shapes.py), so the rare tiny
+    // quotient goes through the IEEE expansion instead: the exact flavour holds EVERY bit of the oracle, subnormal values
+    // included, for 5 % of its VALU-bound sweeps (seven guarded quotients per cell; 85 -> 80 Gcells/s at 16384²; until
+    // round 4 only the A/B library was built this way). -DARMON_LOOSE_SUBNORMAL: the unguarded form, for measurements.
     __device__ __forceinline__ double quo_t(double a) const
     {
         const double q = quo(a);
-#ifdef ARMON_STRICT_SUBNORMAL
+#ifndef ARMON_LOOSE_SUBNORMAL
         // (an exact zero — the transverse velocity of Sod, a fluid at rest — is the same zero either way and stays on the fast path)
         if (__builtin_expect(__builtin_fabs(q) < 0x1p-960 && a != 0., 0)) return a / b;
 #endif

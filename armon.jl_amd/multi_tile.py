@@ -330,7 +330,7 @@ class NativeRcclExchanger:
                                                 C.c_void_p(dev.stream), C.byref(self.handle)))
             if any(params.periodic):
                 check(L.armon_hip_mgpu_set_periodic(self.handle, int(params.periodic[0]), int(params.periodic[1])))
-        except (_lib.SolverException, RuntimeError) as e:
+        except Exception as e:           # ANY local failure must still reach the all_gather every other rank is waiting in
             err = e
         ready = [None] * dist.get_world_size(group)
         dist.all_gather_object(ready, err is None, group=group)
@@ -338,7 +338,11 @@ class NativeRcclExchanger:
             self.close()
             raise _lib.SolverException("cpp", f"native RCCL group: local initialisation failed on rank(s) "
                                               f"{[r for r, ok in enumerate(ready) if not ok]}" + (f": {err}" if err else ""))
-        check(L.armon_hip_mgpu_connect(self.handle, ident))
+        try:
+            check(L.armon_hip_mgpu_connect(self.handle, ident))
+        except BaseException:
+            self.close()                 # the prepared handle (context, streams, scratch) does not outlive a failed connect
+            raise
         # the group made its own context on that same stream; sweeps stay on params.device (same stream → same order)
         rank, coords, nb = C.c_int(), (C.c_int * 2)(), (C.c_int * 4)()
         check(L.armon_hip_mgpu_tile_info(self.handle, 0, C.byref(rank), C.byref(coords), C.byref(nb)))

@@ -237,7 +237,9 @@ class ArmonParameters:
                       placement_min_bytes=256 << 20, placement_rounds=8, graph_cycles=False, **options):
         """``device_id``: GPU ordinal (default LOCAL_RANK or 0). ``use_fused_sweep``: run each sweep as
         the fused HIP kernel instead of the 5 staged kernels. ``exact_arithmetic=True``: IEEE division/sqrt
-        and no FMA contraction in the fused sweep (bit-identical to the staged path and to the CPU oracle);
+        and no FMA contraction in the fused sweep — bit-identical to the staged path and to the CPU oracle, every bit,
+        subnormal values included (quotients that can fall below the normal range take the IEEE expansion; the
+        unguarded form of rounds 1-3, one subnormal unit off in 1 run of 800, is the build flag -DARMON_LOOSE_SUBNORMAL);
         the default tuned arithmetic (shared 1-ulp reciprocals, FMAs) stays within the reference's own
         golden-file tolerance (atol 1e-13, rtol 4 eps on the Sod family). ``placement_tries``: how many
         placements of the state vectors in HBM ``init_test`` may try (0/1 = take the first; see

@@ -728,6 +728,8 @@ def graph_cycles_usable(params):
         return False
     if params.use_MPI or any(n != PROC_NULL for n in params.neighbours.values()):
         return False
+    if not getattr(params.device, "owns_ctx", True):      # a tile context of a group: its stream is the group's, not ours to capture
+        return False
     return params.silent > 1 and params.animation_step == 0 and not params.compare and not params.kernel_callbacks
 
 
@@ -810,12 +812,18 @@ def time_loop_graph(params, grid, _after_handover=None):
             key = (cycle % n_parities, grid.data["rho"].ptr == origin)
             if key not in graphs:
                 check(dev._L.armon_hip_graph_begin(dev.ctx))
+                held, g = grid.data["rho"].ptr, C.c_void_p()
                 try:
                     enqueue_cycle(cycle)
-                finally:
-                    g = C.c_void_p()
-                    rc = dev._L.armon_hip_graph_end(dev.ctx, C.byref(g))
-                check(rc)
+                except BaseException:
+                    # leave no capture open, no graph behind and the ping-pong where it was: a caller that catches the
+                    # error finds the state it had before this cycle
+                    if dev._L.armon_hip_graph_end(dev.ctx, C.byref(g)) == 0 and g:
+                        dev._L.armon_hip_graph_destroy(g)
+                    if grid.data["rho"].ptr != held:
+                        grid.swap_state()
+                    raise
+                check(dev._L.armon_hip_graph_end(dev.ctx, C.byref(g)))
                 graphs[key] = g
                 # the capture only recorded the cycle: undo its ping-pong bookkeeping, then replay it for real below
                 for _ in range(swaps_per_cycle):
@@ -853,7 +861,13 @@ def time_loop_graph(params, grid, _after_handover=None):
                         final = prev
                 batch += 1
                 if final is None and cycle - start_cycle > params.maxcycle + 2 * GRAPH_BATCH:
-                    final = state_at((batch - 1) & 1)
+                    # every cycle the run could hold has been enqueued and the device still does not say `done`: the state
+                    # machine is not stepping (it cannot happen with the kernels as they are; it must not pass for a result)
+                    last = state_at((batch - 1) & 1)
+                    if not last.done:
+                        solver_error("time", f"the device-resident time loop did not finish within maxcycle = {params.maxcycle} "
+                                             f"cycles (device state: cycle {last.cycle}, time {last.time}, dt {last.current_dt})")
+                    final = last
             last = state_at((batch - 1) & 1)
             final = last if last.done else final
         except BaseException:

@@ -483,7 +483,7 @@ def main():
                                f"({scaling} scaling)",
                    "baseline_config": args.config,
                    "path": "staged (5 kernels/sweep)" if args.staged else "fused sweep",
-                   "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle)" if args.exact
+                   "arithmetic": "exact (IEEE div/sqrt, no contraction; bit-identical to the CPU oracle, subnormal values included)" if args.exact
                    else "tuned (shared 1-ulp reciprocals + FMA; within the reference's golden tolerance)",
                    "process_grid": list(P), "sweeps_per_step": 2, "cells_per_gpu": cells_local,
                    "hbm_placement": placement, "device": r["device"], "halo_exchange": halo_mode,

@@ -272,7 +272,10 @@ typedef struct {
     int32_t nghost;          /* ghost layers of the arrays (>= scheme·projection stencil)       */
     int32_t bc_low, bc_high; /* 1: physical boundary on the low/high side of `axis` → mirror BC
                                 applied in-tile; 0: ghosts already hold neighbour data (halo)   */
-    int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to staged  */
+    int32_t exact;           /* 1: IEEE division/sqrt, no contraction: bit-identical to the staged kernels and to the
+                                CPU restatement of the reference — every bit, subnormal results included
+                                (-DARMON_LOOSE_SUBNORMAL at build time trades that last case for 5 %);
+                                0: tuned (shared 1-ulp reciprocals + FMA, within the reference's golden tolerance) */
     int32_t x_kernel;        /* X-sweep kernel form: 0 = the one the library runs (lanes along x, DPP
                                 shifts, 2 cells per lane). 3 (1 cell per lane) and 2 (LDS-transposed
                                 march) are measured alternatives that exist only in the A/B build
@@ -344,7 +347,12 @@ ARMON_API int armon_hip_dt_state_step_f32(armon_ctx*, armon_dt_state* state_dev,
 
 /* Stream capture of whatever the caller enqueues on the context's stream between _begin and _end (sweeps with dt_state,
  * the state step) into an executable graph; _launch replays it on that stream. Everything captured must already have run
- * once outside a capture (the library sizes its scratch on first use and cannot allocate while capturing). */
+ * once outside a capture (the library sizes its scratch on first use and cannot allocate while capturing).
+ * The context must own its stream (armon_hip_init with stream = NULL): _begin refuses a caller-supplied or null stream.
+ * Invalidation rule: the captured kernels hold the address of the context's reduction scratch, so while a graph of a
+ * context is alive that scratch cannot grow — a launch on the same context that needs more of it (a larger block, a
+ * first dtCFL) FAILS with ARMON_ERR_INVALID_ARG instead of moving it; run such launches before capturing, or destroy the
+ * graph first. A graph must be destroyed before its context. */
 typedef struct armon_graph armon_graph;
 ARMON_API int armon_hip_graph_begin(armon_ctx*);
 ARMON_API int armon_hip_graph_end(armon_ctx*, armon_graph** graph);

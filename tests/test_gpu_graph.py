@@ -152,3 +152,74 @@ def test_graph_mode_is_refused_where_the_host_must_act_inside_a_cycle(tmp_path):
     for o in (dict(silent=1), dict(animation_step=2, output_dir=str(tmp_path)), dict(use_fused_sweep=False), dict(graph_cycles=False)):
         kw = dict(dict(silent=5, graph_cycles=True), **o)
         assert not graph_cycles_usable(armon_amd.ArmonParameters(test="Sod", N=(32, 32), **kw))
+
+
+def test_graph_capture_guards():
+    """The rules next to armon_hip_graph_* in include/armon_hip.h: capture only on a context that owns its stream; while a
+    graph of a context is alive its reduction scratch may not move (a launch that would grow it fails instead of leaving the
+    graph with a dangling pointer); after the graph is destroyed the same launch goes through."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.blocking import Axis
+    from armon_amd.device import HIPDevice
+    from armon_amd.solver import BlockGrid, init_test, sweep_desc
+    L = armon_amd.lib()
+    # a context on a borrowed stream: capture is refused, and so is graph mode on the host side
+    owner = HIPDevice(0)
+    borrowed = HIPDevice(0, stream=owner.stream)
+    assert L.armon_hip_graph_begin(borrowed.ctx) != 0
+    assert b"owns its stream" in L.armon_hip_last_error()
+    borrowed.close()
+    owner.close()
+    # a small block captured, then a much larger one on the same context: its dt tracking needs more partials
+    small = armon_amd.ArmonParameters(test="Sod_circ", N=(64, 64), silent=5)
+    gs = BlockGrid(small)
+    init_test(small, gs)
+    dev = small.device
+    d = sweep_desc(small, gs, Axis.Y, 1e-4, 1.0 / 64, emit_dt=True)
+    _lib.check(small.fn("sweep")(dev.ctx, C.byref(d)))                  # runs once outside the capture, as the rule says
+    _lib.check(L.armon_hip_graph_begin(dev.ctx))
+    _lib.check(small.fn("sweep")(dev.ctx, C.byref(d)))
+    g = C.c_void_p()
+    _lib.check(L.armon_hip_graph_end(dev.ctx, C.byref(g)))
+    big = armon_amd.ArmonParameters(test="Sod_circ", N=(4096, 2048), silent=5, ctx=dev.ctx)
+    gb = BlockGrid(big)
+    init_test(big, gb, tune=False)
+    db = sweep_desc(big, gb, Axis.X, 1e-5, 1.0 / 4096, emit_dt=True)    # one pair of maxima per WAVE: far more than 64² needed
+    assert big.fn("sweep")(dev.ctx, C.byref(db)) != 0
+    assert b"captured graph" in L.armon_hip_last_error()
+    _lib.check(L.armon_hip_graph_launch(dev.ctx, g))                     # the graph is still whole
+    small.wait()
+    _lib.check(L.armon_hip_graph_destroy(g))
+    _lib.check(big.fn("sweep")(dev.ctx, C.byref(db)))                    # … and now the scratch may grow
+    small.wait()
+    # `big` only borrowed the context: its vectors go before the context's owner does
+    import gc
+    del db, gb, big
+    gc.collect()
+
+
+def test_dt_state_is_refused_by_the_kernels_that_ignore_it():
+    """The LDS X march and the whole-cycle kernels of the A/B build never read armon_dt_state: a descriptor that carries
+    one is an error there, not a silently wrong time step."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.blocking import Axis
+    from armon_amd.solver import BlockGrid, init_test, sweep_desc
+    with _lib.alt_kernels():
+        L = armon_amd.lib()
+        params = armon_amd.ArmonParameters(test="Sod_circ", N=(64, 48), silent=5)
+        grid = BlockGrid(params)
+        init_test(params, grid)
+        state = params.device.zeros(C.sizeof(_lib.DtState) // 8)
+        dx = sweep_desc(params, grid, Axis.X, 1.0, 1.0 / 64)
+        dy = sweep_desc(params, grid, Axis.Y, 1.0, 1.0 / 48)
+        dx.dt_state = state.ptr
+        dx.x_kernel = 2
+        assert params.fn("sweep")(params.device.ctx, C.byref(dx)) != 0 and b"dt_state" in L.armon_hip_last_error()
+        dx.x_kernel = 0
+        if params.suffix == "":
+            assert L.armon_hip_cycle_xy(params.device.ctx, C.byref(dx), C.byref(dy)) != 0 and b"dt_state" in L.armon_hip_last_error()
+        params.wait()

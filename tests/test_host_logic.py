@@ -291,3 +291,15 @@ def test_bench_refuses_an_impossible_process_grid_before_touching_a_gpu():
     assert r.returncode != 0 and "cannot form that process grid" in r.stderr and r.stdout == ""
     r = subprocess.run([sys.executable, bench, "--gpus", "4"], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "torch.distributed.run" in r.stderr and r.stdout == ""
+
+
+def test_design_md_quotes_what_the_committed_profiles_say():
+    """DESIGN.md's measured tables sit between `evidence` markers and are injected from profiles/r04_* by
+    tools/evidence_table.py: a number typed by hand, or a profile re-collected without re-injecting, fails here."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "4", "--check", os.path.join(ROOT, "DESIGN.md")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "4"], capture_output=True, text=True)
+    assert gen.returncode == 0 and gen.stdout == open(os.path.join(ROOT, "profiles", "r04_evidence.md")).read()
