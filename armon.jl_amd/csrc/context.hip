@@ -117,7 +117,7 @@ int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value)
     else if (!strcmp(knob, "ARMON_Y_SEG")) ctx->tune_y_seg = value > 0 ? value : 0;
     else if (!strcmp(knob, "ARMON_SWEEP_ALIGN")) ctx->tune_align = value < 0 ? 1 : (value != 0);
     else if (!strcmp(knob, "ARMON_Y_COLS1")) ctx->tune_y_cols1 = value > 0;
-    else if (!strcmp(knob, "ARMON_X_XCD")) ctx->tune_x_xcd = value > 0;
+    else if (!strcmp(knob, "ARMON_X_XCD")) ctx->tune_x_xcd = value < 0 ? -1 : (value > 0);
     else if (!strcmp(knob, "ARMON_X_ROWS")) ctx->tune_x_rows = (value == 1 || value == 2) ? value : 0;
     else if (!strcmp(knob, "ARMON_Y_SX")) ctx->tune_y_sx = (value == 1 || value == 2) ? value : 0;
     else ARMON_REQUIRE(false, "unknown tuning knob '%s'", knob);

@@ -78,6 +78,7 @@ struct sweep_args {
     int64_t x_first;               // X sweep: first cell of strip 0 (<= o_lo, sector-aligned in the ghosted row)
     int32_t xshift;                // Y sweep: columns the block origin is moved left (line-aligned row segments)
     int32_t xcd_remap;             // X sweep: XCD-aware workgroup placement (ARMON_X_XCD)
+    int32_t gx = 0, gy = 0;        // X sweep: the launch's grid (gridDim comes from the dispatch packet: one more dependent scalar load)
     int32_t x_wg_along_x = 0;      // X sweep: a workgroup = kXSRows consecutive strips of one row (else: one strip of kXSRows rows)
     int32_t x_row_align = 0;       // X sweep: strip origins aligned row by row (row pitch not a multiple of a 64-B sector)
     int32_t y_sx = 0;              // Y sweep: rows are stored in sector-aligned windows handed over through LDS (see k_sweep_y)
@@ -665,8 +666,8 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     // XCD k (ids ≡ k mod 8) gets the whole row k: neighbouring strips then follow each other on the same L2.
     unsigned vbx = blockIdx.x, vby = blockIdx.y;
     if (a.xcd_remap) {
-        const unsigned G = gridDim.x, chunk = vby & ~7u;
-        if (chunk + 8 <= gridDim.y) {                          // whole groups only: the last rows keep the plain mapping
+        const unsigned G = (unsigned)a.gx, chunk = vby & ~7u;
+        if (chunk + 8 <= (unsigned)a.gy) {                     // whole groups only: the last rows keep the plain mapping
             const unsigned local = (vby - chunk) * G + vbx;    // 0 .. 8G-1 in dispatch order
             vby = chunk + (local & 7u);
             vbx = local >> 3;
@@ -817,7 +818,7 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
     if (TRACK) {
         const real au = red::wave_reduce<red::op_max>(cfl.au), av = red::wave_reduce<red::op_max>(cfl.av);
         if (threadIdx.x == 0) {
-            const int64_t wave_id = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kXSRows + threadIdx.y;
+            const int64_t wave_id = ((int64_t)blockIdx.y * a.gx + blockIdx.x) * kXSRows + threadIdx.y;
             st2(a.partials + 2 * wave_id, au, av);
         }
     }
@@ -838,7 +839,7 @@ __device__ __forceinline__ void preload_x_args(const sweep_args& a, int niter)
 {
 #if ARMON_X_PRELOAD
     asm volatile("" ::"s"(a.nx), "s"(a.ny), "s"(a.row_len), "s"(a.g), "s"(a.bc_low), "s"(a.bc_high), "s"(a.emit), "s"(a.o_lo),
-                 "s"(a.o_hi), "s"(a.x_first), "s"(a.xcd_remap), "s"(a.x_wg_along_x), "s"(a.x_row_align), "s"(niter));
+                 "s"(a.o_hi), "s"(a.x_first), "s"(a.xcd_remap), "s"(a.x_wg_along_x), "s"(a.x_row_align), "s"(niter), "s"(a.gx), "s"(a.gy));
     asm volatile("" ::"s"(a.dt), "s"(a.dx), "s"(a.gamma), "s"(a.inv_dx), "s"(a.dt_dx), "s"(a.rho_in), "s"(a.ua_in), "s"(a.ut_in),
                  "s"(a.E_in), "s"(a.rho_out), "s"(a.ua_out), "s"(a.ut_out), "s"(a.E_out));
 #endif
@@ -1280,8 +1281,11 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
         const int64_t per_block = 16 - 2 * PIPE::LAG;
         dim3 grid((unsigned)((a.o_hi - a.x_first + per_block - 1) / per_block), (unsigned)((a.ny + 4 * kXSRows - 1) / (4 * kXSRows)));
         *n_blocks = (int64_t)grid.x * grid.y * kXSRows;
+        sweep_args b = a;
+        b.gx = (int32_t)grid.x;
+        b.gy = (int32_t)grid.y;
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK, true, 1>),
-                           grid, dim3(64, kXSRows), 0, ctx->stream, a, 1);
+                           grid, dim3(64, kXSRows), 0, ctx->stream, b, 1);
         return check_launch("sweep_x_dpp (narrow)");
     }
     const int halo = k1 ? PIPE::LAG : 4;
@@ -1291,21 +1295,24 @@ int launch(armon_ctx* ctx, const sweep_args& a, int axis, int64_t* n_blocks)
     if (a.x_wg_along_x && !k1 && niter == 1)                  // kXSRows strips of one row per workgroup
         grid = dim3((unsigned)((a.o_hi - x_lowest + kXSRows * per_block - 1) / (kXSRows * per_block)), (unsigned)a.ny);
     *n_blocks = (int64_t)grid.x * grid.y * kXSRows;          // one pair of maxima per wave
+    sweep_args b = a;
+    b.gx = (int32_t)grid.x;
+    b.gy = (int32_t)grid.y;
 #if defined(ARMON_ALT_KERNELS) && !defined(ARMON_ONLY_HEADLINE)
     if (k1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 1, TRACK, false>),
-                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+                           grid, dim3(64, kXSRows), 0, ctx->stream, b, niter);
     else if (niter > 1)
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK, false>),
-                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+                           grid, dim3(64, kXSRows), 0, ctx->stream, b, niter);
     else
 #endif
 #ifdef ARMON_XS_MULTI
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK, false>),
-                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+                           grid, dim3(64, kXSRows), 0, ctx->stream, b, niter);
 #else
         hipLaunchKernelGGL((k_sweep_x_dpp<PIPE::SCHEME, PIPE::LIM, PIPE::PROJ, PIPE::EOS, PIPE::kExact, 2, TRACK, true>),
-                           grid, dim3(64, kXSRows), 0, ctx->stream, a, niter);
+                           grid, dim3(64, kXSRows), 0, ctx->stream, b, niter);
 #endif
     return check_launch("sweep_x_dpp");
 }
@@ -1497,7 +1504,13 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     }
     a.xshift = (X || !align) ? 0 : d->nghost % 16;
     a.x_first = X ? (align ? a.o_lo - (a.o_lo + d->nghost) % 8 : a.o_lo) : 0;
-    a.xcd_remap = ctx->tune_x_xcd;
+    // XCD-aware placement of the X sweep's workgroups (sweep_x_dpp_body): neighbouring strips of a row — they share a 128-B
+    // line, a strip's loads start 32 B before its sector-aligned stores — then follow each other on ONE XCD's L2 instead of
+    // being fetched from the fabric by two. With one strip per wave that is the whole over-fetch of the sweep: 18.90 ->
+    // 17.3 GB per launch by counters at 16384² (1.10x -> 1.01x the algorithmic bytes), time equal to 1.5 % better
+    // (profiles/r04_ab_x_xcd.txt). fp64 only: fp32 shares its lines inside a workgroup instead (x_wg_along_x below).
+    const bool want_along_x = ctx->tune_x_rows == 2 || (ctx->tune_x_rows == 0 && sizeof(real) == 4);
+    a.xcd_remap = ctx->tune_x_xcd < 0 ? (sizeof(real) == 8 && !want_along_x) : ctx->tune_x_xcd;
     // origins row by row when one origin cannot align every row (the one-strip-per-wave form only; the A/B forms keep one)
     a.x_row_align = 0;
 #ifndef ARMON_XS_MULTI
@@ -1512,8 +1525,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     // workgroup shape of the X sweep (profiles/r03_ab_x_workgroup_shape.txt): 4 consecutive strips of one row pay for fp32
     // (1.54 -> 1.43 ms at 16384²: a 512-B strip shares a quarter of its 128-B lines with its neighbours) and not for fp64
     // (equal at 16384² and 4096 x 8192, +3 % at 8192²), which keeps one strip of 4 rows. ARMON_X_ROWS: 1 / 2 force a shape.
-    const bool want_along_x = ctx->tune_x_rows == 2 || (ctx->tune_x_rows == 0 && sizeof(real) == 4);
-    a.x_wg_along_x = (X && want_along_x && d->ny <= 65535 && !ctx->tune_x_xcd) ? 1 : 0;              // grid.y carries the rows
+    a.x_wg_along_x = (X && want_along_x && d->ny <= 65535 && !a.xcd_remap) ? 1 : 0;              // grid.y carries the rows
     a.partials = nullptr;
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));

@@ -499,7 +499,9 @@ def main():
     # next to `value` (which stays the weak one: `scaling` names it). The weak line is the contract and is complete at
     # this point: a second workload that raises on some rank, or hangs in a collective because it did, must not cost
     # it — a watchdog prints the line as it stands and ends the process after --strong-timeout seconds.
-    if world > 1 and scaling == "weak" and not args.no_strong:
+    # (ARMON_BENCH_FORCE_STRONG=1, with ARMON_BENCH_FORCE_DIST=1: the second workload with ONE rank over RCCL — the rehearsal of
+    # tearing the library's communicators down and building them again inside one process, which one GPU allows)
+    if (world > 1 or os.environ.get("ARMON_BENCH_FORCE_STRONG") == "1") and scaling == "weak" and not args.no_strong:
         import threading
 
         def bail():

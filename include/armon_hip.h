@@ -95,7 +95,8 @@ ARMON_API void* armon_hip_stream(armon_ctx* ctx);                              /
  * "ARMON_XS_NITER" strips per wave of the X sweep (values > 1 select the multi-strip form with its prefetch buffer, which only
  * the A/B build libarmon_hip_alt.so carries; the product library runs one strip per wave), "ARMON_Y_SEG" rows per run of the Y march (0 = automatic),
  * "ARMON_SWEEP_ALIGN" 0 = unaligned block/strip origins, "ARMON_Y_COLS1" 1 = fp32 Y march with one column per lane,
- * "ARMON_X_XCD" 1 = XCD-aware workgroup order of the X sweep, "ARMON_X_ROWS" workgroup shape of the X sweep: 1 = one strip of
+ * "ARMON_X_XCD" XCD-aware workgroup order of the X sweep: 1 = on, 0 = off, < 0 = automatic (on for fp64, off for fp32, whose
+ * workgroups share their lines themselves), "ARMON_X_ROWS" workgroup shape of the X sweep: 1 = one strip of
  * 4 rows, 2 = 4 consecutive strips of one row, 0 = automatic (the former for fp64, the latter for fp32),
  * "ARMON_Y_SX" store exchange of the Y march (rows stored in sector-aligned windows handed over through LDS): 1 = always,
  * 2 = never, 0 = automatic (when the row pitch is not a multiple of a 64-B sector).
