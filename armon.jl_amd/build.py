@@ -15,7 +15,7 @@ OUT = os.path.join(HERE, "libarmon_hip.so")
 # arithmetic in its strict form since round 4: quotients that can fall below the normal range take the IEEE expansion,
 # csrc/physics.hpp.)
 OUT_ALT = os.path.join(HERE, "libarmon_hip_alt.so")
-ALT_SOURCES = ("fused_sweep_f64.hip", "fused_sweep_f32.hip", "staged_kernels.hip")     # the translation units the defines change
+ALT_SOURCES = ("fused_sweep_f64.hip", "fused_sweep_f32.hip")     # the translation units the define changes
 ALT_FLAGS = ["-DARMON_ALT_KERNELS"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
