@@ -400,7 +400,7 @@ def main():
                     help="strong scaling: the global grid stays --cells² (or --global) whatever the number of GPUs")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1, default workload: skip the strong-scaling workload timed after the weak one")
-    ap.add_argument("--strong-timeout", type=float, default=300.,
+    ap.add_argument("--strong-timeout", type=float, default=180.,
                     help="seconds the strong-scaling workload may take before the weak line is printed without it")
     ap.add_argument("--require-native", action="store_true",
                     help="N > 1: exit with status 3 (after printing the line) when the halos do not travel through the "
