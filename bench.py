@@ -348,6 +348,9 @@ def run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live
                 "sweeps_timed": sweeps_timed, "mean_launch_ms": round(mean_ms, 4),
                 "per_kernel_ms": {k: round(sum(v) / max(cycles_timed * (2 if args.staged else 1), 1), 4)
                                   for k, v in durs.items()}}     # per sweep of that axis (staged: per call)
+    # each kernel against the peak on its own (the slower one is the dominant kernel of the contract; `frac` above is the mean sweep)
+    roofline["per_kernel_frac"] = {k: round(bpc * cells_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                   for k, ms in roofline["per_kernel_ms"].items() if ms > 0 and not args.staged}
     if copy_gbps:
         roofline["stream_copy_GBps_this_device"] = round(copy_gbps, 1)     # measured right after the timed region
         roofline["frac_of_stream_copy"] = round(achieved / copy_gbps, 4)

@@ -30,6 +30,7 @@ def test_single_gpu_line_carries_the_contract():
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and ro["bytes_per_cell"] == 64
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and set(ro["per_kernel_ms"]) == {"sweep_x", "sweep_y"}
     assert "traffic" in ro and "strong" not in d
+    assert set(ro["per_kernel_frac"]) == {"sweep_x", "sweep_y"} and all(0 < v < 1 for v in ro["per_kernel_frac"].values())
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     sc = d["self_check"]

@@ -223,3 +223,50 @@ def test_dt_state_is_refused_by_the_kernels_that_ignore_it():
         if params.suffix == "":
             assert L.armon_hip_cycle_xy(params.device.ctx, C.byref(dx), C.byref(dy)) != 0 and b"dt_state" in L.armon_hip_last_error()
         params.wait()
+
+
+def test_a_failed_capture_leaves_the_context_and_the_ping_pong_usable(monkeypatch):
+    """An exception while a cycle is being captured must end the capture, leave no graph behind and put the ping-pong of
+    the two state sets back: the same grid then runs host-driven to the result of an undisturbed run."""
+    import armon_amd
+    from armon_amd import solver
+    from armon_amd.solver import BlockGrid, init_test, time_loop
+    kw = dict(test="Sod_circ", N=(80, 56), maxcycle=21, axis_splitting="Strang", silent=5)
+    ref_params = armon_amd.ArmonParameters(**kw)
+    ref_grid = BlockGrid(ref_params)
+    init_test(ref_params, ref_grid)
+    ref = time_loop(ref_params, ref_grid)
+    ref_rho = ref_grid.real_view(ref_grid.device_to_host(("rho",))["rho"]).copy()
+
+    params = armon_amd.ArmonParameters(graph_cycles=True, **kw)
+    grid = BlockGrid(params)
+    init_test(params, grid)
+    real = solver._graph_sweep_descs
+    calls = {"n": 0}
+
+    def failing(p, g, parity, state_ptr):
+        calls["n"] += 1
+        descs = real(p, g, parity, state_ptr)          # swaps the state sets as it goes (3 sweeps: an odd number)
+        raise RuntimeError("injected while capturing")
+
+    monkeypatch.setattr(solver, "_graph_sweep_descs", failing)
+    origin = grid.data["rho"].ptr
+    with pytest.raises(RuntimeError, match="injected"):
+        time_loop(params, grid)
+    assert calls["n"] == 1
+    # cycles 0 and 1 ran host-driven (2 x 3 sweeps: back on the first set); the aborted capture's 3 swaps were undone
+    assert grid.data["rho"].ptr == origin
+    monkeypatch.setattr(solver, "_graph_sweep_descs", real)
+    # the stream is out of capture mode: a capture can start again (and is closed again, graph or not)
+    import ctypes as C
+    L = armon_amd.lib()
+    assert L.armon_hip_graph_begin(params.device.ctx) == 0
+    g = C.c_void_p()
+    if L.armon_hip_graph_end(params.device.ctx, C.byref(g)) == 0:
+        L.armon_hip_graph_destroy(g)
+    # from the initial state again, host-driven: the undisturbed run's bits
+    params.graph_cycles = False
+    init_test(params, grid, tune=False)
+    out = time_loop(params, grid)
+    assert out[:3] == ref[:3]
+    assert np.array_equal(grid.real_view(grid.device_to_host(("rho",))["rho"]), ref_rho)
