@@ -148,6 +148,16 @@ static double* dmalloc(size_t n)
     return p;
 }
 
+// physically contiguous allocation (hipDeviceMallocContiguous); NULL when the runtime refuses the flag or the size
+static double* dmalloc_contig(size_t n)
+{
+    double* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags((void**)&p, n * 8, hipDeviceMallocContiguous);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    CK(hipMemset(p, 0, n * 8));
+    return p;
+}
+
 int main(int argc, char** argv)
 {
     int inst = 3;
@@ -186,6 +196,55 @@ int main(int argc, char** argv)
             run_pair<0>(T, tag, A2B, B2A);
         }
         for (double* p : v) CK(hipFree(p));
+    }
+
+    if (only.find("flatc") != std::string::npos) {
+        // the 8 flat vectors, each PHYSICALLY CONTIGUOUS: is the level then the same for every instance and process?
+        const long pitch = nx + 2 * g;
+        std::vector<double*> v;
+        for (int k = 0; k < 8 * inst; k++) {
+            double* p = dmalloc_contig((size_t)pitch * rows + 512);
+            if (!p) { printf("flatc: hipExtMallocWithFlags(hipDeviceMallocContiguous) refused vector %d\n", k); break; }
+            v.push_back(p);
+        }
+        for (int i = 0; i + 1 <= (int)v.size() / 8; i++) {
+            lay A2B, B2A;
+            for (int k = 0; k < 4; k++) {
+                A2B.in[k] = v[8 * i + k]; A2B.out[k] = v[8 * i + 4 + k];
+                B2A.in[k] = v[8 * i + 4 + k]; B2A.out[k] = v[8 * i + k];
+            }
+            A2B.rpitch = B2A.rpitch = pitch;
+            snprintf(tag, sizeof tag, "flatc #%d (in order) base %%16MiB=%zuK", i, ((size_t)v[8 * i] % (16u << 20)) >> 10);
+            run_pair<0>(T, tag, A2B, B2A);
+            for (int k = 0; k < 4; k++) {
+                A2B.in[k] = v[8 * i + 2 * k]; A2B.out[k] = v[8 * i + 2 * k + 1];
+                B2A.in[k] = v[8 * i + 2 * k + 1]; B2A.out[k] = v[8 * i + 2 * k];
+            }
+            snprintf(tag, sizeof tag, "flatc #%d (even/odd)", i);
+            run_pair<0>(T, tag, A2B, B2A);
+        }
+        for (double* p : v) CK(hipFree(p));
+        // ONE contiguous slab holding the 8 vectors back to back at a padded stride
+        for (long padMiB : {0L, 2L, 6L, 10L}) {
+            const size_t stride = (size_t)pitch * rows + (size_t)padMiB * 131072;
+            double* S = dmalloc_contig(8 * stride + 512);
+            if (!S) { printf("flatc: contiguous slab of %.1f GB refused\n", 8.0 * stride * 8 / 1e9); break; }
+            lay A2B, B2A;
+            for (int k = 0; k < 4; k++) {
+                A2B.in[k] = S + (2 * k) * stride; A2B.out[k] = S + (2 * k + 1) * stride;
+                B2A.in[k] = A2B.out[k]; B2A.out[k] = A2B.in[k];
+            }
+            A2B.rpitch = B2A.rpitch = pitch;
+            snprintf(tag, sizeof tag, "slabc pad %ld MiB (even/odd)", padMiB);
+            run_pair<0>(T, tag, A2B, B2A);
+            for (int k = 0; k < 4; k++) {
+                A2B.in[k] = S + k * stride; A2B.out[k] = S + (4 + k) * stride;
+                B2A.in[k] = A2B.out[k]; B2A.out[k] = A2B.in[k];
+            }
+            snprintf(tag, sizeof tag, "slabc pad %ld MiB (in order)", padMiB);
+            run_pair<0>(T, tag, A2B, B2A);
+            CK(hipFree(S));
+        }
     }
 
     if (want("rows")) {
