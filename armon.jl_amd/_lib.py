@@ -74,6 +74,18 @@ class HaloDesc(C.Structure):
                 ("vars", C.c_void_p * 8)]
 
 
+class CyclePlan(C.Structure):
+    """armon_cycle_plan — one solver cycle of every local tile (include/armon_hip.h, armon_hip_mgpu_cycle)."""
+    _fields_ = [("n_sweeps", C.c_int32), ("emit_p", C.c_int32), ("emit_dt", C.c_int32), ("overlap", C.c_int32),
+                ("axis", C.c_int32 * 4), ("dt", C.c_double * 4), ("next_axis", C.c_int32), ("event_slot", C.c_int32),
+                ("event_ctx", C.c_void_p), ("dt_host", C.c_void_p), ("dt_event_slot", C.c_int32), ("reserved", C.c_int32)]
+
+
+class TileCycle(C.Structure):
+    """armon_tile_cycle(_f32) — the full X and Y sweep descriptors of one local tile."""
+    _fields_ = [("x", SweepDesc), ("y", SweepDesc)]
+
+
 MGPU_ID_BYTES = 256
 
 _lib = None
@@ -156,6 +168,10 @@ SIGNATURES = {
     "armon_hip_halo_exchange_finish_edge": (_ci, [_vp, _ci, C.POINTER(HaloDesc)]),
     "armon_hip_mgpu_edge_join": (_ci, [_vp, C.POINTER(_vp)]),
     "armon_hip_mgpu_allreduce_host": (_ci, [_vp, _ci, _ci, C.POINTER(_dbl)]),
+    "armon_hip_mgpu_cycle": (_ci, [_vp, C.POINTER(CyclePlan), C.POINTER(TileCycle)]),
+    "armon_hip_mgpu_drain": (_ci, [_vp, C.POINTER(TileCycle)]),
+    "armon_hip_mgpu_set_threads": (_ci, [_vp, _ci]),
+    "armon_hip_mgpu_sync": (_ci, [_vp]),
     "armon_hip_halo_ranges": (_ci, [_i64, _i64, _ci, _ci, C.POINTER(Range), C.POINTER(Range), C.POINTER(_i64)]),
 }
 
@@ -179,7 +195,7 @@ def _add_f32_signatures():
                 conv.append(a)
         SIGNATURES["armon_hip_" + name + "_f32"] = (res, conv)
     for name in ("halo_exchange_start", "halo_exchange_finish", "halo_exchange", "dt_allreduce",
-                 "halo_exchange_finish_edge", "mgpu_edge_join"):
+                 "halo_exchange_finish_edge", "mgpu_edge_join", "mgpu_cycle", "mgpu_drain"):
         SIGNATURES["armon_hip_" + name + "_f32"] = SIGNATURES["armon_hip_" + name]
     SIGNATURES["armon_hip_sweep_f32"] = SIGNATURES["armon_hip_sweep"]
     SIGNATURES["armon_hip_tune_placement_f32"] = SIGNATURES["armon_hip_tune_placement"]

@@ -19,7 +19,7 @@ import time as _time
 import numpy as np
 
 from . import _lib
-from ._lib import HaloDesc, check
+from ._lib import CyclePlan, HaloDesc, TileCycle, check
 from .blocking import Axis, Side, first_side, last_side, sides_along
 from .parameters import PROC_NULL, ArmonParameters
 from . import solver as S
@@ -35,6 +35,45 @@ def _halo_descs(params_list, grids, names):
         for k, f in enumerate(names):
             d.vars[k] = g.data[f].ptr
     return descs
+
+
+def tile_cycle_descs(params_list, grids):
+    """``armon_tile_cycle[n]``: per tile the descriptors of a full X and a full Y sweep from the set of vectors that holds the
+    state NOW into its partner (armon_hip_mgpu_cycle fills in the steps, the sides and the cycle's outputs)."""
+    tcs = (TileCycle * len(grids))()
+    for tc, p, g in zip(tcs, params_list, grids):
+        tc.x = S.sweep_desc(p, g, Axis.X, 0., p.cell_size(0), emit_p=True, emit_dt=True)
+        tc.y = S.sweep_desc(p, g, Axis.Y, 0., p.cell_size(1), emit_p=True, emit_dt=True)
+    return tcs
+
+
+def cycle_plan(params, gdt, last_cycle, prefetch=True, dt_host=None):
+    """``armon_cycle_plan`` of the cycle ``gdt`` is about to run (ref split_axes + update_solver_state!,
+    src/axis_splitting.jl:24-46, src/solver_state.jl:339-345). ``dt_host``: pinned array of two elements, the landing zone
+    of the next CFL step (slot = parity of the cycle; the event of that slot is recorded on tile 0's edge context)."""
+    sweeps = S.split_axes(params.axis_splitting, gdt.cycle)
+    plan = CyclePlan(n_sweeps=len(sweeps), emit_p=int(last_cycle), emit_dt=int(not params.cst_dt),
+                     overlap=int(params.overlap_halo), next_axis=-1, event_slot=-1, dt_event_slot=-1)
+    if dt_host is not None and not params.cst_dt:
+        plan.dt_host = dt_host.ptr + (gdt.cycle & 1) * np.dtype(params.data_type).itemsize
+        plan.dt_event_slot = S.DT_EVENT_SLOT + (gdt.cycle & 1)
+    for k, (axis, dt_factor) in enumerate(sweeps):
+        plan.axis[k] = int(axis) - 1
+        plan.dt[k] = gdt.current_dt * params.T(dt_factor)
+    if prefetch and not last_cycle and params.overlap_halo:
+        plan.next_axis = int(S.split_axes(params.axis_splitting, gdt.cycle + 1)[0][0]) - 1
+    names = ["sweep_x" if a == Axis.X else "sweep_y" for a, _ in sweeps]
+    for cb in params.kernel_callbacks:        # timers that can hand out event slots (bench.py's EventTimer)
+        if hasattr(cb, "reserve"):
+            plan.event_slot = cb.reserve(names)
+            plan.event_ctx = params.device.ctx      # the pool the timer reads (a rank's own context shares the tile's stream)
+    return plan, len(sweeps)
+
+
+def native_cycle_usable(params):
+    """The native cycle has two forms of a sweep with remote sides: interior + edge stream (overlap), or in order."""
+    return (params.use_fused_sweep and getattr(params, "native_cycle", True)
+            and (not params.overlap_halo or params.edge_stream))
 
 
 class TileGroup:
@@ -78,6 +117,22 @@ class TileGroup:
             g.global_dt = self.global_dt               # one clock for every tile (ref GlobalTimeStep is global)
         self.dt_host = None
         self.dt_inflight = {}
+        self._tcs = {}              # tile-cycle descriptors per ping-pong parity (key: where tile 0's rho lives)
+
+    def set_threads(self, on):
+        """One host thread per tile inside ``armon_hip_mgpu_cycle`` (default) or everything from the calling thread."""
+        check(self._L.armon_hip_mgpu_set_threads(self.handle, int(on)))
+
+    def _tile_cycles(self):
+        key = tuple(g.data["rho"].ptr for g in self.grids)
+        if key not in self._tcs:
+            self._tcs[key] = tile_cycle_descs(self.params, self.grids)
+        return self._tcs[key]
+
+    def drain(self):
+        """Complete an exchange the last native cycle posted ahead and no cycle consumed."""
+        if self.handle and native_cycle_usable(self.root):
+            check(self._fn("mgpu_drain")(self.handle, self._tile_cycles()))
 
     def close(self):
         if self.handle:
@@ -125,8 +180,7 @@ class TileGroup:
         check(self._fn("dt_allreduce")(self.handle, ptrs))
 
     def wait(self):
-        for p in self.params:
-            p.wait()
+        check(self._L.armon_hip_mgpu_sync(self.handle))       # compute and transfer streams of every tile
 
     # ---- solver ---------------------------------------------------------------------------------------------------
     def init_test(self):
@@ -221,7 +275,11 @@ class TileGroup:
         self.dt_inflight[cycle] = S.DT_EVENT_SLOT + (cycle & 1)
 
     def _take_dt_readback(self, posted_in_cycle):
-        self.root.device.event_sync(self.dt_inflight.pop(posted_in_cycle))
+        slot = self.dt_inflight.pop(posted_in_cycle)
+        if isinstance(slot, tuple):                       # posted by armon_hip_mgpu_cycle: the event lives in tile 0's edge context
+            check(self._L.armon_hip_event_sync(self._edge_ctx[0], slot[1]))
+        else:
+            self.root.device.event_sync(slot)
         return float(self.dt_host.array[posted_in_cycle & 1])
 
     def solver_cycle(self, last_cycle=True):
@@ -236,6 +294,21 @@ class TileGroup:
             self._local_dt_to_device()
             self._post_dt_readback()
             gdt.update_dt(self._take_dt_readback(gdt.cycle))
+        if native_cycle_usable(p0):
+            # the whole cycle of every tile in one library call (one host thread per tile inside)
+            if self.dt_host is None:
+                self.dt_host = p0.device.pinned(2, p0.data_type)
+            plan, n_sweeps = cycle_plan(p0, gdt, last_cycle, dt_host=self.dt_host)
+            check(self._fn("mgpu_cycle")(self.handle, C.byref(plan), self._tile_cycles()))
+            if n_sweeps & 1:
+                for g in self.grids:
+                    g.swap_state()
+            if not p0.cst_dt:
+                # the library reduced the next CFL step and posted its read-back on tile 0's transfer stream
+                self.dt_inflight[gdt.cycle] = ("edge", plan.dt_event_slot)
+                if deferred:
+                    gdt.update_dt(self._take_dt_readback(gdt.cycle - 1))
+            return
         sweeps = S.split_axes(p0.axis_splitting, gdt.cycle)
         for k, (axis, dt_factor) in enumerate(sweeps):
             dx = p0.cell_size(int(axis) - 1)
@@ -267,6 +340,7 @@ class TileGroup:
                         or p0.T(gdt.time + gdt.current_dt) >= maxtime)
             self.solver_cycle(last_cycle=ends)
             gdt.next_cycle()
+        self.drain()
         self.wait()
         return _time.perf_counter_ns() - t1
 
@@ -350,6 +424,7 @@ class NativeRcclExchanger:
         assert [params.neighbours[s] for s in (Side.Left, Side.Right, Side.Bottom, Side.Top)] == list(nb)
         self.edge_ctx = C.c_void_p(L.armon_hip_mgpu_edge_ctx(self.handle, 0))      # this tile's transfer stream as a context
         self.edge_dt = int(L.armon_hip_mgpu_edge_dt(self.handle, 0))
+        self._tcs = {}
 
     def _fn(self, name):
         return getattr(self._L, "armon_hip_" + name + self.params.suffix)
@@ -392,6 +467,37 @@ class NativeRcclExchanger:
     def set_chaos(self, max_delay_us, seed=0):
         """Test aid: random busy-wait kernels in front of the group's stream operations (armon_hip_mgpu_set_chaos)."""
         check(self._L.armon_hip_mgpu_set_chaos(self.handle, int(max_delay_us), int(seed)))
+
+    # the whole cycle of this rank's tile in one library call (solver.solver_cycle takes this branch when it can)
+    native_cycle = True
+
+    def _tile_cycles(self):
+        key = self.grid.data["rho"].ptr
+        if key not in self._tcs:
+            self._tcs[key] = tile_cycle_descs([self.params], [self.grid])
+        return self._tcs[key]
+
+    def cycle(self, gdt, last_cycle):
+        """One solver cycle (exchanges, sweeps, the global minimum of the next CFL step and its read-back, posted on the
+        transfer stream) → the event slot of that read-back in the edge context, or None (cst_dt)."""
+        grid = self.grid
+        if grid.dt_host is None:
+            grid.dt_host = self.params.device.pinned(2, self.params.data_type)
+        plan, n_sweeps = cycle_plan(self.params, gdt, last_cycle, dt_host=grid.dt_host)
+        check(self._fn("mgpu_cycle")(self.handle, C.byref(plan), self._tile_cycles()))
+        if n_sweeps & 1:
+            grid.swap_state()
+        return None if self.params.cst_dt else plan.dt_event_slot
+
+    def event_sync(self, slot):
+        check(self._L.armon_hip_event_sync(self.edge_ctx, slot))
+
+    def drain(self):
+        """End of a run: complete the exchange posted ahead, and let the transfer stream finish (the last reduction and its
+        read-back are still on it; ``params.wait()`` only covers the compute stream)."""
+        if self.handle and native_cycle_usable(self.params):
+            check(self._fn("mgpu_drain")(self.handle, self._tile_cycles()))
+            check(self._L.armon_hip_mgpu_sync(self.handle))
 
     def allreduce_host(self, values, op):
         v = (C.c_double * len(values))(*values)

@@ -234,7 +234,7 @@ class ArmonParameters:
     # ref src/parameters.jl:766-778 — backend specific options (like ext/ArmonKokkos.jl:83-87)
     def _init_backend(self, device_id=None, use_fused_sweep=True, exact_arithmetic=False, stream=None,
                       placement_tries=16, stream_ordered_halo=True, ctx=None, native_halo=True, overlap_halo=True, edge_stream=True,
-                      placement_min_bytes=256 << 20, placement_rounds=8, graph_cycles=False, **options):
+                      placement_min_bytes=256 << 20, placement_rounds=8, graph_cycles=False, native_cycle=True, **options):
         """``device_id``: GPU ordinal (default LOCAL_RANK or 0). ``use_fused_sweep``: run each sweep as
         the fused HIP kernel instead of the 5 staged kernels. ``exact_arithmetic=True``: IEEE division/sqrt
         and no FMA contraction in the fused sweep — bit-identical to the staged path and to the CPU oracle, every bit,
@@ -263,6 +263,9 @@ class ArmonParameters:
         # dt state machine on the device + each cycle replayed from a hipGraph (solver.time_loop_graph): one host call per
         # cycle instead of one per kernel plus a scalar read-back — what small grids are bound by
         self.graph_cycles = bool(graph_cycles)
+        # tile groups / RCCL ranks: a whole cycle (exchanges, sweeps, dt minimum) enqueued by ONE library call
+        # (armon_hip_mgpu_cycle) instead of call by call from this host mirror
+        self.native_cycle = bool(native_cycle)
         self.stream_ordered_halo = bool(stream_ordered_halo)   # RCCL: order the exchange on the stream, no host syncs
         self.shared_stream = False
         self.backend_options = dict(device_id=device_id, use_fused_sweep=self.use_fused_sweep,

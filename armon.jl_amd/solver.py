@@ -608,6 +608,8 @@ def prefetch_halo(params, grid):
 
 def drain_halo(grid):
     """Complete a prefetched exchange nobody consumed (end of a run, change of plan)."""
+    if getattr(grid.comm, "native_cycle", False):
+        grid.comm.drain()                        # what the library's own cycle posted ahead
     if grid.halo_prefetch is not None:
         grid.comm.finish(grid.halo_prefetch[1])
         grid.halo_prefetch = None
@@ -647,7 +649,11 @@ def post_dt_readback(params, grid):
 
 def take_dt_readback(params, grid, posted_in_cycle):
     """Global CFL step posted by ``posted_in_cycle`` (blocks only if the GPU has not got there yet)."""
-    params.device.event_sync(grid.dt_inflight.pop(posted_in_cycle))
+    slot = grid.dt_inflight.pop(posted_in_cycle)
+    if isinstance(slot, tuple):                   # posted by armon_hip_mgpu_cycle on the tile's transfer stream (its edge context)
+        grid.comm.event_sync(slot[1])
+    else:
+        params.device.event_sync(slot)
     local_dt = float(grid.dt_host.array[posted_in_cycle & 1])
     if grid.comm is not None and getattr(grid.comm, "stream_ordered", False):
         return local_dt                                           # already the minimum over the ranks
@@ -678,6 +684,17 @@ def solver_cycle(params, grid, last_cycle=True):
         next_time_step(params, grid)
     if _checkpoint(params, grid, "time_step"):
         return True
+    if params.use_MPI and getattr(grid.comm, "native_cycle", False) and not params.compare:
+        from .multi_tile import native_cycle_usable
+        if native_cycle_usable(params):
+            # the library's own group: exchanges, sweeps and the all-reduce of the next CFL step in ONE call
+            # (armon_hip_mgpu_cycle); what is left for the host is the read-back of that scalar, one cycle late
+            slot = grid.comm.cycle(gdt, last_cycle)
+            if slot is not None:
+                grid.dt_inflight[gdt.cycle] = ("edge", slot)
+                if deferred:
+                    gdt.update_dt(take_dt_readback(params, grid, gdt.cycle - 1))
+            return False
     sweeps = split_axes(params.axis_splitting, gdt.cycle)
     for k, (axis, dt_factor) in enumerate(sweeps):
         # update_solver_state!: ref src/solver_state.jl:339-345

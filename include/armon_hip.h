@@ -515,6 +515,50 @@ ARMON_API int armon_hip_mgpu_edge_join_f32(armon_mgpu*, float* const* dt_dev);
 ARMON_API int armon_hip_dt_allreduce(armon_mgpu*, double* const* dt_dev);
 ARMON_API int armon_hip_dt_allreduce_f32(armon_mgpu*, float* const* dt_dev);
 
+/* A whole solver cycle of every LOCAL tile in one call — solver_cycle (ref src/solver.jl:288-320) on the fused path:
+ * for each sweep of the cycle (ref split_axes, src/axis_splitting.jl:24-46) the halo exchange along its axis (ref
+ * block_ghost_exchange, src/halo_exchange.jl:323-354), the interior of the sweep while the faces travel, the unpack and the
+ * LAG-wide strips on the transfer stream, the join; after the last sweep the global minimum of the next CFL step (ref
+ * src/solver_state.jl:89-111) — the calls above in the order the edge-stream protocol prescribes, enqueued natively. A
+ * group of several local tiles is driven by ONE HOST THREAD PER TILE (created by the first cycle; ARMON_MGPU_THREADS=0 or
+ * armon_hip_mgpu_set_threads(group, 0) keeps everything in the calling thread): eight devices fed from one thread cost
+ * eight times the enqueue time of one, more than the 0.75 ms of GPU work of the tile of a 16384² grid on 8 GPUs.
+ * Nothing is waited for on the host; the call returns when everything is enqueued.
+ *  plan  : n_sweeps (1..3), axis[s] and dt[s] of each sweep (dt = current_dt x the splitting's factor, rounded as the run's
+ *          precision rounds it), emit_p (last cycle of a run: the last sweep materialises p, ref saved_vars), emit_dt (the
+ *          last sweep reduces the next CFL step and the group takes its minimum — folded, reduced and copied to dt_host on
+ *          the TRANSFER streams: the compute streams go from this cycle's last sweep to the next cycle's first without
+ *          waiting for it, as the reference's MPI_Iallreduce is waited for one cycle later; afterwards every tile's
+ *          dt_cfl_out holds the minimum, ordered on that tile's transfer stream; 0 with cst_dt), overlap (0 = unpack and
+ *          sweep in order on the compute stream), next_axis = axis of the NEXT cycle's first sweep, whose exchange is
+ *          posted at the end of this call and consumed by the next one (-1 = none; a posted exchange nobody consumes is
+ *          completed by armon_hip_mgpu_drain), event_slot >= 0: events event_slot + 2s / + 2s + 1 of event_ctx's pool
+ *          are recorded on local tile 0's compute stream around sweep s (armon_hip_event_elapsed_ms reads them), -1 = none.
+ *  tiles : per local tile the descriptors of a FULL X and a FULL Y sweep of that tile as armon_hip_sweep takes them, with
+ *          *_in = the vectors that hold the state when the call is made and *_out = their partners (the same two sets in x
+ *          and y); p_out / dt_cfl_out name where emit_p / emit_dt put their results; dt, bc_low / bc_high, out_lo / out_hi,
+ *          dt_accumulate are set by the library (the sides from the group's topology). After the call the state is in the
+ *          *_out set when n_sweeps is odd, in the *_in set when it is even. */
+typedef struct {
+    int32_t n_sweeps, emit_p, emit_dt, overlap;
+    int32_t axis[4];             /* [0 .. n_sweeps) used */
+    double  dt[4];
+    int32_t next_axis, event_slot;
+    armon_ctx* event_ctx;        /* whose event pool event_slot names: a context on local tile 0's compute stream; NULL = that tile's own */
+    void*   dt_host;             /* emit_dt: pinned host slot (one element of the run's precision, armon_hip_malloc_host) the   */
+    int32_t dt_event_slot;       /* global minimum is copied to, and the event of local tile 0's EDGE context (armon_hip_mgpu_edge_ctx)
+                                    recorded behind that copy (-1 = none): armon_hip_event_sync(edge_ctx, slot), then read *dt_host */
+    int32_t reserved;
+} armon_cycle_plan;
+typedef struct { armon_sweep_desc x, y; } armon_tile_cycle;
+typedef struct { armon_sweep_desc_f32 x, y; } armon_tile_cycle_f32;
+ARMON_API int armon_hip_mgpu_cycle(armon_mgpu*, const armon_cycle_plan* plan, const armon_tile_cycle* tiles);
+ARMON_API int armon_hip_mgpu_cycle_f32(armon_mgpu*, const armon_cycle_plan* plan, const armon_tile_cycle_f32* tiles);
+ARMON_API int armon_hip_mgpu_drain(armon_mgpu*, const armon_tile_cycle* tiles);      /* tiles: descriptors whose *_in hold the state */
+ARMON_API int armon_hip_mgpu_drain_f32(armon_mgpu*, const armon_tile_cycle_f32* tiles);
+ARMON_API int armon_hip_mgpu_sync(armon_mgpu*);       /* host waits for the compute AND transfer streams of every local tile */
+ARMON_API int armon_hip_mgpu_set_threads(armon_mgpu*, int on);                        /* 1 / 0; < 0 = by the environment */
+
 /* Host-value all-reduce over the PROCESSES of the group (the conservation sums, ref src/reductions.jl:317-320);
  * op 0 = sum, 1 = min; count <= 16; synchronous; the caller folds its own local tiles first. */
 ARMON_API int armon_hip_mgpu_allreduce_host(armon_mgpu*, int op, int count, double* values);

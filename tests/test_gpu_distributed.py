@@ -227,3 +227,84 @@ def test_single_rank_over_native_rccl_equals_plain_run(tmp_path):
     assert int(t["cycles"]) == ref.cycles and float(t["dt"]) == ref.last_dt
     for k in ("rho", "u", "v", "E", "p"):
         assert np.array_equal(t[k], ref.data.real_view(host[k])), k
+
+
+# ---- the whole cycle of every tile in one library call (armon_hip_mgpu_cycle) -------------------------------------------
+# The default of every fused tile-group test above. Here the three drivers of the same protocol are held against each other
+# and against the single block: the host mirror calling the library step by step (native_cycle=False: exchange_start,
+# interior, finish_edge, strips, edge_join, dt_allreduce), the native cycle from the calling thread, and the native cycle
+# with one host thread per tile (barriers between the steps).
+@pytest.mark.parametrize("driver", ["host-calls", "native-serial", "native-threads"])
+@pytest.mark.parametrize("P,N,test,opts", [
+    ((2, 2), (48, 40), "Sod_circ", dict(maxcycle=12)),
+    ((4, 2), (128, 64), "Sedov", dict(maxcycle=10, axis_splitting="Godunov")),     # the first sweep's axis alternates: prefetch X, then Y
+    ((3, 3), (61, 59), "Sod_circ", dict(maxcycle=9, axis_splitting="Strang")),     # 3 sweeps: the state ends in the other set
+    ((3, 2), (20, 20), "Sod_circ", dict(maxcycle=8)),                              # tiles too small to overlap: in-order form per tile
+    ((2, 2), (96, 80), "Bizarrium", dict(maxcycle=8, data_type="float32")),
+    ((2, 1), (64, 24), "Sod", dict(maxcycle=8, cst_dt=True, Dt=1e-4)),             # no dt reduction at all
+    ((1, 3), (37, 241), "Sod_circ", dict(maxcycle=8, overlap_halo=False)),
+    ((4, 1), (96, 32), "Sod_circ", dict(maxcycle=7, axis_splitting="X_only")),     # one sweep per cycle, always prefetched
+])
+def test_tile_cycle_drivers_agree(P, N, test, opts, driver):
+    import armon_amd
+    from armon_amd.multi_tile import TileGroup
+    o = dict(opts, exact_arithmetic=True)
+    ref = armon_amd.armon(armon_amd.ArmonParameters(test=test, N=N, silent=5, return_data=True, **o))
+    host = ref.data.device_to_host(("rho", "u", "v", "E", "p"))
+    group = TileGroup(P, test=test, N=N, silent=5, native_cycle=driver != "host-calls", **o)
+    try:
+        group.set_threads(driver == "native-threads")
+        stats = group.run()
+        assert stats.cycles == ref.cycles and stats.last_dt == ref.last_dt and stats.final_time == ref.final_time
+        got = group.gather()
+        for k in ("rho", "u", "v", "E", "p"):
+            assert np.array_equal(got[k], ref.data.real_view(host[k])), k
+    finally:
+        group.close()
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_threaded_tile_cycles_survive_injected_delays(seed):
+    """One host thread per tile + busy-wait kernels of up to 300 µs in front of the group's stream operations."""
+    import armon_amd
+    from armon_amd.multi_tile import TileGroup
+    kw = dict(test="Bizarrium", N=(160, 96), maxcycle=10, silent=5)
+    ref = armon_amd.armon(armon_amd.ArmonParameters(return_data=True, **kw))
+    host = ref.data.device_to_host(("rho", "u", "v", "E", "p"))
+    group = TileGroup((4, 2), force_peer_copy=seed == 5, **kw)
+    try:
+        group.set_threads(True)
+        group.set_chaos(300, seed)
+        stats = group.run()
+        assert stats.cycles == ref.cycles and stats.last_dt == ref.last_dt
+        got = group.gather()
+        for k in ("rho", "u", "v", "E", "p"):
+            assert np.array_equal(got[k], ref.data.real_view(host[k])), k
+    finally:
+        group.close()
+
+
+def test_tile_cycle_refuses_what_it_cannot_run():
+    """Errors of the one-call cycle reach the caller as SolverException(:cpp) with the tile named, and leave the group usable."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    from armon_amd.multi_tile import TileGroup, cycle_plan, tile_cycle_descs
+    group = TileGroup((2, 1), test="Sod", N=(64, 24), silent=5, maxcycle=4)
+    try:
+        group.init_test()
+        group.global_dt.reset()
+        plan, _ = cycle_plan(group.root, group.global_dt, last_cycle=False)
+        plan.n_sweeps = 5
+        with pytest.raises(_lib.SolverException, match="1 to 3 sweeps"):
+            _lib.check(group._fn("mgpu_cycle")(group.handle, C.byref(plan), group._tile_cycles()))
+        tcs = tile_cycle_descs(group.params, group.grids)
+        tcs[1].x.rho_out = tcs[1].x.rho_in                      # in == out: the sweep of tile 1 refuses it, from its own thread
+        plan, _ = cycle_plan(group.root, group.global_dt, last_cycle=False)
+        plan.dt[0] = plan.dt[1] = 1e-4
+        with pytest.raises(_lib.SolverException, match="tile 1"):
+            _lib.check(group._fn("mgpu_cycle")(group.handle, C.byref(plan), tcs))
+        stats = group.run()                                     # and the group still runs
+        assert stats.cycles == 4
+    finally:
+        group.close()

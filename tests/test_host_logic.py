@@ -281,16 +281,34 @@ def test_file_paths_and_time_step_file(tmp_path):
 
 
 def test_bench_refuses_an_impossible_process_grid_before_touching_a_gpu():
-    """bench.py --grid must multiply to the number of ranks (checked before any device is created), and N > 1 without
-    the launcher is refused with a message instead of running something else."""
+    """bench.py --grid must multiply to the number of ranks (checked before any device is created or any child started),
+    and --transport peer is one process: refused under a launcher."""
     import subprocess
     import sys
     bench = os.path.join(ROOT, "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, bench, "--gpus", "1", "--grid", "2x2"], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "cannot form that process grid" in r.stderr and r.stdout == ""
-    r = subprocess.run([sys.executable, bench, "--gpus", "4"], capture_output=True, text=True, env=env)
-    assert r.returncode != 0 and "torch.distributed.run" in r.stderr and r.stdout == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--grid", "3x1"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "cannot form that process grid" in r.stderr and r.stdout == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--transport", "peer"], capture_output=True, text=True,
+                       env={**env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "without a launcher" in r.stderr and r.stdout == ""
+
+
+def test_bench_launches_its_own_ranks_and_reports_failure_with_a_status():
+    """`python bench.py --gpus 2` from a bare shell starts the ranks itself (child torch.distributed.run), falls back to the
+    in-process transport when they give no line, and — here, where there is no GPU at all — ends with a non-zero status,
+    an empty stdout and both attempts named on stderr. (The successful forms run on the GPU box: tests/test_gpu_bench.py.)"""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--cells", "64", "--steps", "1", "--warmup", "0", "--launch-timeout", "240"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and r.stdout == ""
+    assert "rank launch under torch.distributed.run gave no line" in r.stderr and "falling back to --transport peer" in r.stderr
+    assert "the in-process (peer) run gave no line either" in r.stderr
 
 
 def test_design_md_quotes_what_the_committed_profiles_say():
