@@ -105,6 +105,7 @@ SIGNATURES = {
     "armon_hip_device_name": (_ci, [_vp, C.c_char_p, C.c_size_t]),
     "armon_hip_stream": (_vp, [_vp]),
     "armon_hip_set_tuning": (_ci, [_vp, C.c_char_p, _ci]),
+    "armon_hip_get_tuning": (_ci, [_vp, C.c_char_p, C.POINTER(_ci)]),
     "armon_hip_malloc": (_ci, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "armon_hip_free": (_ci, [_vp, _vp]),
     "armon_hip_memcpy": (_ci, [_vp, _vp, _vp, C.c_size_t, _ci]),

@@ -124,6 +124,21 @@ int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value)
     return ARMON_OK;
 }
 
+int armon_hip_get_tuning(armon_ctx* ctx, const char* knob, int* value)
+{
+    ARMON_REQUIRE(ctx && knob && value, "NULL argument");
+    if (!strcmp(knob, "ARMON_XS_NITER")) *value = ctx->tune_xs_niter;
+    else if (!strcmp(knob, "ARMON_Y_SEG")) *value = ctx->tune_y_seg;
+    else if (!strcmp(knob, "ARMON_SWEEP_ALIGN")) *value = ctx->tune_align;
+    else if (!strcmp(knob, "ARMON_Y_COLS1")) *value = ctx->tune_y_cols1;
+    else if (!strcmp(knob, "ARMON_X_XCD")) *value = ctx->tune_x_xcd;
+    else if (!strcmp(knob, "ARMON_X_ROWS")) *value = ctx->tune_x_rows;
+    else if (!strcmp(knob, "ARMON_Y_SX")) *value = ctx->tune_y_sx;
+    else if (!strcmp(knob, "Y_RUN_ROWS")) *value = ctx->tune_y_seg > 0 ? ctx->tune_y_seg : ctx->seg_value;
+    else ARMON_REQUIRE(false, "unknown tuning knob '%s'", knob);
+    return ARMON_OK;
+}
+
 int armon_hip_destroy(armon_ctx* ctx)
 {
     if (!ctx) return ARMON_OK;

@@ -609,20 +609,31 @@ k_init_test(armon_range r, int test, int64_t row_length, int64_t nx, int64_t ny,
         d.x[i] = x;
         d.y[i] = y;
         bool ghost = !(Ix >= 1 && Ix <= nx && Iy >= 1 && Iy <= ny);
-        d.mask[i] = ghost ? T(0.) : T(1.);
+        // (the vectors outside the state may be absent — the reference's `vars_to_zero` list, src/kernels.jl:142-144,188-191:
+        // a host that runs the fused sweeps never reads us, ps, work_1..4, mask, and c, g only on its first cycle)
+        if (d.mask) d.mask[i] = ghost ? T(0.) : T(1.);
         if (test == ARMON_TEST_DEBUG_INDEXES) {
             T gi = (T)(gx + gy * gN_x + 1);
-            d.rho[i] = gi; d.E[i] = gi; d.u[i] = gi; d.v[i] = gi; d.p[i] = gi; d.c[i] = gi; d.g[i] = gi;
+            d.rho[i] = gi; d.E[i] = gi; d.u[i] = gi; d.v[i] = gi;
+            if (d.p) d.p[i] = gi;
+            if (d.c) d.c[i] = gi;
+            if (d.g) d.g[i] = gi;
         } else {
             bool hi = region_high(test, x + dXx / 2, y + dXy / 2, sedov_r);
             d.rho[i] = hi ? tp.hi_rho : tp.lo_rho;
             d.E[i] = hi ? tp.hi_E : tp.lo_E;
             d.u[i] = hi ? tp.hi_u : tp.lo_u;
             d.v[i] = hi ? tp.hi_v : tp.lo_v;
-            d.p[i] = 0.; d.c[i] = 0.; d.g[i] = 0.;
+            if (d.p) d.p[i] = 0.;
+            if (d.c) d.c[i] = 0.;
+            if (d.g) d.g[i] = 0.;
         }
-        d.us[i] = 0.; d.ps[i] = 0.;
-        d.work_1[i] = 0.; d.work_2[i] = 0.; d.work_3[i] = 0.; d.work_4[i] = 0.;
+        if (d.us) d.us[i] = 0.;
+        if (d.ps) d.ps[i] = 0.;
+        if (d.work_1) d.work_1[i] = 0.;
+        if (d.work_2) d.work_2[i] = 0.;
+        if (d.work_3) d.work_3[i] = 0.;
+        if (d.work_4) d.work_4[i] = 0.;
     }
 }
 
@@ -874,7 +885,7 @@ int init_test_impl(armon_ctx* ctx, armon_range r, int test, int64_t row_length, 
     ARMON_REQUIRE(test >= ARMON_TEST_SOD && test <= ARMON_TEST_DEBUG_INDEXES, "unknown test tag %d", test);
     static_assert(sizeof(BD) == 16 * sizeof(T*), "block data = 16 pointers");
     T* const* arrs = reinterpret_cast<T* const*>(d);
-    for (int k = 0; k < 16; k++) ARMON_REQUIRE(arrs[k] != nullptr, "NULL array in block data (field %d)", k);
+    for (int k = 0; k < 6; k++) ARMON_REQUIRE(arrs[k] != nullptr, "NULL array in block data (field %d: x, y, rho, u, v, E are required)", k);
     block_ptrs<T> bp;
     memcpy(&bp, d, sizeof(bp));
     // ref src/tests.jl:84-121

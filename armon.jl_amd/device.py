@@ -82,6 +82,15 @@ class HIPDevice:
     def event_sync(self, slot):
         check(self._L.armon_hip_event_sync(self.ctx, int(slot)))
 
+    def get_tuning(self, knob):
+        v = C.c_int()
+        check(self._L.armon_hip_get_tuning(self.ctx, knob.encode(), C.byref(v)))
+        return v.value
+
+    def y_run_rows(self):
+        """Rows per run of this context's last Y sweep (armon_hip_get_tuning "Y_RUN_ROWS")."""
+        return self.get_tuning("Y_RUN_ROWS")
+
     def pinned(self, n, dtype=np.float64):
         """``n`` elements of page-locked host memory as a numpy array (freed with the returned object)."""
         return PinnedArray(self, n, dtype)

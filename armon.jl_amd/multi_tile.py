@@ -294,6 +294,9 @@ class TileGroup:
             self._local_dt_to_device()
             self._post_dt_readback()
             gdt.update_dt(self._take_dt_readback(gdt.cycle))
+            if fused and gdt.cycle == 0:
+                for g in self.grids:
+                    g.release_scratch()          # c, g: only the EOS + dtCFL of cycle 0 needed them
         if native_cycle_usable(p0):
             # the whole cycle of every tile in one library call (one host thread per tile inside)
             if self.dt_host is None:

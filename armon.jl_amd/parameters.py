@@ -355,11 +355,17 @@ def cart_neighbours(coords, dims, periodic=(False, False)):
     }
 
 
-def memory_required(N, nghost=4, data_type=np.float64, fused=True):
-    """Device bytes for one block (ref ``memory_required``, src/blocking/block_grid.jl): 16 arrays in
-    the staged layout, +4 ping-pong arrays when the fused sweep is used."""
-    n = (N[0] + 2 * nghost) * (N[1] + 2 * nghost)
-    return n * np.dtype(data_type).itemsize * (16 + (4 if fused else 0))
+def memory_required(N, nghost=4, data_type=np.float64, fused=True, transient=False):
+    """Device bytes for one block (ref ``memory_required``, src/blocking/block_grid.jl): the 16 ``BlockData`` vectors on the
+    staged path; on the fused path the 7 it touches (x, y, rho, u, v, E, p) + 4 ping-pong partners of the state — the
+    other nine (us, ps, work_1..4, mask; c, g after the first cycle) are only allocated when something reads them.
+    ``transient=True``: the peak instead — + c, g during cycle 0, or the 8 spare vectors of the placement search of
+    ``init_test`` (blocks whose vectors reach 256 MiB), whichever is larger."""
+    n = (N[0] + 2 * nghost) * (N[1] + 2 * nghost) * np.dtype(data_type).itemsize
+    if not fused:
+        return n * 16
+    spares = 8 if n >= (256 << 20) else 2
+    return n * (11 + (spares if transient else 0))
 
 
 def proc_grid_for(world):

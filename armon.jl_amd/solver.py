@@ -105,6 +105,40 @@ def split_axes(splitting, cycle):
     solver_error("config", f"Unknown splitting method: '{splitting}'")
 
 
+# what the fused path touches in every run: the saved variables (ref saved_vars, src/blocking/blocks.jl:49) and the state
+FUSED_FIELDS = ("x", "y", "rho", "u", "v", "E", "p")
+
+
+class _Fields(dict):
+    """The 16 ``BlockData`` vectors by name. On the staged path all of them exist from the start, as in the reference (ref
+    src/blocking/blocks.jl:36-44). On the fused path only the seven of ``FUSED_FIELDS`` do — ``us, ps, work_1..4, mask`` are
+    never touched by a fused run, ``c, g`` only by the EOS + dtCFL of cycle 0 — and any other is allocated on first access,
+    holding what ``init_test`` would have left in it (zeros; 0 / 1 for ``mask``): a 16384² block keeps 11 + the 8 transient
+    spares of the placement search instead of 20 + 8 vectors (config 5's global grid on one GPU: 172 -> 95 GB), while the
+    ``BlockData`` the C ABI sees stays 16 pointers (NULL = not in ``vars_to_zero``)."""
+
+    def __init__(self, grid, names):
+        super().__init__()
+        self._grid = grid
+        for f in names:
+            self[f] = grid.params.device.empty(grid.size.n_cells, grid.params.data_type)
+
+    def __missing__(self, key):
+        if key not in FIELDS:
+            raise KeyError(key)
+        grid = self._grid
+        a = grid.params.device.zeros(grid.size.n_cells, grid.params.data_type)
+        if key == "mask" and grid.initialised:
+            g = grid.size.ghosts
+            nx, ny = grid.size.real_size
+            m = np.zeros((ny + 2 * g, nx + 2 * g), dtype=grid.params.data_type)
+            m[g:g + ny, g:g + nx] = 1
+            a.copy_from_host(m.ravel())
+        self[key] = a
+        grid.lazy.add(key)
+        return a
+
+
 class BlockGrid:
     """One block per GPU (ref BlockGrid with use_cache_blocking=false, src/blocking/block_grid.jl:352-355):
     the 16 ``BlockData`` vectors (ref src/blocking/blocks.jl:18-44) in HBM, plus the 4 ping-pong state
@@ -116,7 +150,9 @@ class BlockGrid:
         dev = params.device
         n = self.size.n_cells
         dt_ = params.data_type
-        self.data = {f: dev.empty(n, dt_) for f in FIELDS}
+        self.initialised = False               # init_test has run (a vector created later is given its initial content)
+        self.lazy = set()                      # fused path: the vectors created on first access
+        self.data = _Fields(self, FUSED_FIELDS if params.use_fused_sweep else FIELDS)
         self.alt = {f: dev.empty(n, dt_) for f in STATE_VARS} if params.use_fused_sweep else None
         self.placement = None                  # report of tune_placement (bench / tests)
         self.global_dt = GlobalTimeStep(params)
@@ -130,10 +166,20 @@ class BlockGrid:
         return C.c_void_p(self.data[name].ptr)
 
     def block_data_ptrs(self):
+        """``armon_block_data``: the vectors that exist (NULL for those the fused path has not needed yet)."""
         bd = BlockDataPtrs()
         for f in FIELDS:
-            setattr(bd, f, self.data[f].ptr)
+            if f in self.data:
+                setattr(bd, f, self.data[f].ptr)
         return bd
+
+    def release_scratch(self, names=("c", "g")):
+        """Fused path: free vectors that were only created on the way (``c, g`` by the EOS + dtCFL of cycle 0)."""
+        for f in names:
+            if f in self.lazy and f in self.data:
+                self.params.wait()
+                self.data.pop(f).free()
+                self.lazy.discard(f)
 
     def swap_state(self):
         """After a fused sweep the fresh state lives in ``alt``: exchange the roles."""
@@ -261,8 +307,10 @@ class BlockGrid:
         return a.reshape(self.size.size[1], self.size.size[0])[g:g + ny, g:g + nx]
 
     def memory_required(self):
-        n = self.size.n_cells * self.params.data_type.itemsize
-        return n * (16 + (4 if self.alt else 0))
+        """Bytes of device memory the block's vectors take (ref memory_required, src/blocking/block_grid.jl): the 16 of
+        ``BlockData`` on the staged path; 7 + 4 ping-pong partners on the fused one (+ any created on first access)."""
+        n = self.size.n_cells * np.dtype(self.params.data_type).itemsize
+        return n * (len(self.data) + (4 if self.alt else 0))
 
 
 # ---- per-block kernel wrappers -----------------------------------------------------------------
@@ -304,6 +352,7 @@ def init_test(params, grid, tune=True):
         else:
             tune_staged_placement(params, grid)
     _init_test_kernel(params, grid)
+    grid.initialised = True
 
 
 def tune_staged_placement(params, grid, min_bytes=None):
@@ -682,6 +731,8 @@ def solver_cycle(params, grid, last_cycle=True):
             return True
     if not deferred:
         next_time_step(params, grid)
+        if params.use_fused_sweep and gdt.cycle == 0:
+            grid.release_scratch()               # c, g: only the EOS + dtCFL of cycle 0 needed them
     if _checkpoint(params, grid, "time_step"):
         return True
     if params.use_MPI and getattr(grid.comm, "native_cycle", False) and not params.compare:

@@ -102,6 +102,9 @@ ARMON_API void* armon_hip_stream(armon_ctx* ctx);                              /
  * 2 = never, 0 = automatic (when the row pitch is not a multiple of a 64-B sector).
  * None of them changes a result bit. */
 ARMON_API int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value);
+/* the current value of a knob; and, read-only, "Y_RUN_ROWS": rows per run the last automatic choice of the Y march took (0
+ * before the first Y sweep of the context) — tests use it to check that a shape really has several runs per column */
+ARMON_API int armon_hip_get_tuning(armon_ctx* ctx, const char* knob, int* value);
 
 /* device array type support: V{T,1}(undef, n) / copyto! (ref src/blocking/blocks.jl:36-44,121-143) */
 ARMON_API int armon_hip_malloc(armon_ctx* ctx, size_t bytes, void** ptr);
@@ -209,7 +212,9 @@ ARMON_API int armon_hip_conservation_vars(armon_ctx*, armon_range, double ds,
  * ref src/kernels.jl:71-145,176-207, src/tests.jl:59-121.
  * `range` = full domain (real+ghost); row_length = Nx+2g; global_pos = 0-based global index of the
  * block's first real cell (ref src/kernels.jl:181-182); global_N = global grid (for DebugIndexes);
- * sedov_r (ref src/tests.jl:15-19) is only read for ARMON_TEST_SEDOV. All 16 arrays are written. */
+ * sedov_r (ref src/tests.jl:15-19) is only read for ARMON_TEST_SEDOV. All 16 arrays are written; x, y, rho, u, v, E are
+ * required, any of the other ten may be NULL and is then skipped — the reference's `vars_to_zero` argument (ref
+ * src/kernels.jl:142-144,188-191): a host that runs the fused sweeps only never reads us, ps, work_1..4 and mask. */
 typedef struct {
     double *x, *y, *rho, *u, *v, *E, *p, *c, *g, *us, *ps, *work_1, *work_2, *work_3, *work_4, *mask;
 } armon_block_data;   /* ref src/blocking/blocks.jl:18-35 (BlockData) */

@@ -301,3 +301,75 @@ def test_baseline_tile_configurations_at_full_size(P, shape, test):
             assert np.array_equal(got[k], full[k]), k
     finally:
         group.close()
+
+
+# ---- problems that vary along BOTH axes, at sizes with many runs per column, many strips per row and several XCD groups ------
+# (parity hole 1.) Every full-size check above is a 1-D problem reduced to a strip; the 2-D problems were held
+# against the oracle up to 1031 x 130 / 770 x 515 only — one run of the Y march per column, fewer than two whole groups of the
+# X sweep's XCD-aware workgroup order. Here the oracle runs the SAME size (all host cores; ≈ 2 GB of host arrays at 4096²):
+#   Sod_circ, Sedov 4096²     : 16 column blocks x 15 runs of 274 rows, 1024 rows of X workgroups = 128 XCD groups
+#   Bizarrium 2048 x 6000     : Y_only, 9 column blocks x >= 10 runs per column, its own EOS
+#   Sod_circ 3000 x 133       : 33 rows of X workgroups + 1 ragged: 4 whole XCD groups and a partial one (ny = 4·8·4 + 5)
+#   Sedov 1500 x 261          : 8 whole groups + 5 rows (ny = 4·8·8 + 5), FreeFlow sides
+# exact arithmetic (fused and staged): every bit of rho, u, v, E, p, dt, time; tuned: the stated 1e-11 x max|field| (SURVEY §8c;
+# the reference's own bar for the 100² goldens is atol 1e-13 / rtol 4 eps, test/reference_data/reference_functions.jl:54-57).
+BIG_2D = [
+    ("Sod_circ", (4096, 4096), {}),
+    ("Sedov", (4096, 4096), {}),
+    ("Bizarrium", (2048, 6000), dict(axis_splitting="Y_only")),
+    ("Sod_circ", (3000, 133), {}),
+    ("Sedov", (1500, 261), dict(axis_splitting="Godunov")),
+]
+_oracle_cache = {}
+
+
+def _oracle_2d(oracle, test, shape, opts):
+    key = (test, shape, tuple(sorted(opts.items())))
+    if key not in _oracle_cache:
+        import os
+        _oracle_cache.clear()                                  # one problem at a time: 2 GB each
+        run, f = oracle.solve(test=test, N=shape, maxcycle=CYCLES, threads=min(32, os.cpu_count() or 8), **opts)
+        _oracle_cache[key] = (run.cycles, run.last_dt, run.final_time,
+                              {k: oracle.real_view(f[k], shape[0], shape[1], G).copy() for k in NAMES})
+    return _oracle_cache[key]
+
+
+@pytest.mark.parametrize("mode", ["fused-exact", "staged", "fused-tuned"])
+@pytest.mark.parametrize("test,shape,opts", BIG_2D, ids=[f"{t}-{s[0]}x{s[1]}" for t, s, _ in BIG_2D])
+def test_two_dimensional_problems_at_scale_against_the_oracle(oracle, test, shape, opts, mode):
+    import armon_amd
+    cycles, last_dt, final_time, ref = _oracle_2d(oracle, test, shape, opts)
+    params = armon_amd.ArmonParameters(test=test, N=shape, maxcycle=CYCLES, silent=5, return_data=True,
+                                       use_fused_sweep=mode != "staged", exact_arithmetic=mode != "fused-tuned", **opts)
+    stats = armon_amd.armon(params)
+    assert stats.cycles == cycles == CYCLES
+    if mode != "fused-tuned":
+        assert stats.last_dt == last_dt and stats.final_time == final_time
+    else:
+        assert abs(stats.last_dt - last_dt) <= 1e-12 * last_dt
+    for k in NAMES:
+        a = stats.data.real_view(stats.data.data[k].to_host())
+        if mode != "fused-tuned":
+            assert np.array_equal(a, ref[k]), f"{k}: {np.count_nonzero(a != ref[k])} cells differ, max {np.abs(a - ref[k]).max()}"
+        else:
+            assert np.abs(a - ref[k]).max() <= 1e-11 * np.abs(ref[k]).max(), k
+        del a
+
+
+def test_y_runs_and_xcd_groups_of_the_2d_shapes():
+    """What the shapes above are chosen for, read back from the library's own launch model: ARMON_Y_SEG / ARMON_X_XCD knobs
+    give the same bits (covered elsewhere); here only the counts, so that a change of the model cannot silently turn these
+    tests into one-run / one-group cases."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, init_test, fused_sweep
+    from armon_amd.blocking import Axis
+    for shape, min_runs in (((4096, 4096), 10), ((2048, 6000), 10)):
+        params = armon_amd.ArmonParameters(test="Sod_circ", N=shape, silent=5, placement_tries=0)
+        grid = BlockGrid(params)
+        init_test(params, grid)
+        fused_sweep(params, grid, Axis.Y, 1e-6, params.cell_size(1))
+        params.wait()
+        seg = params.device.y_run_rows()
+        assert seg > 0 and -(-shape[1] // seg) >= min_runs, (shape, seg)
+    for ny in (133, 261):
+        assert (ny - 5) % 32 == 0 and (ny - 5) // 32 >= 3          # whole groups of 8 rows of 4-row workgroups + a ragged rest

@@ -691,3 +691,25 @@ def test_vectors_that_do_not_start_on_a_sector(N, dtype, offset):
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     for k in results[0][2]:
         assert np.array_equal(results[0][2][k], results[1][2][k]), k
+
+
+def test_fused_path_allocates_only_what_it_touches():
+    """the nine staged-only vectors are created on first access on the fused path (c, g by cycle 0's EOS +
+    dtCFL, released right after), the BlockData of the C ABI stays 16 pointers, and whatever is created later holds what
+    init_test would have left in it."""
+    import armon_amd
+    from armon_amd.solver import BlockGrid, init_test, time_loop, FUSED_FIELDS
+    params = armon_amd.ArmonParameters(test="Sod_circ", N=(96, 64), maxcycle=6, silent=5)
+    grid = BlockGrid(params)
+    assert set(grid.data) == set(FUSED_FIELDS) and grid.memory_required() == 11 * grid.size.n_cells * 8
+    init_test(params, grid)
+    assert set(grid.data) == set(FUSED_FIELDS)
+    time_loop(params, grid)
+    assert set(grid.data) == set(FUSED_FIELDS), set(grid.data)          # c, g came and went
+    g, (nx, ny) = grid.size.ghosts, grid.size.real_size
+    mask = grid.data["mask"].to_host().reshape(ny + 2 * g, nx + 2 * g)  # created now, with its initial content
+    assert mask[g:g + ny, g:g + nx].all() and mask.sum() == nx * ny
+    assert not grid.data["work_3"].to_host().any() and "work_3" in grid.lazy
+    # and the staged path keeps the reference's 16
+    p2 = armon_amd.ArmonParameters(test="Sod_circ", N=(96, 64), maxcycle=6, silent=5, use_fused_sweep=False)
+    assert len(BlockGrid(p2).data) == 16

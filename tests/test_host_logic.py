@@ -234,7 +234,13 @@ def test_cartesian_grid_and_neighbours():
 
 
 def test_memory_required():
-    assert armon_amd.memory_required((16384, 16384), 4) == 20 * 16392 * 16392 * 8
+    """Fused path: x, y, rho, u, v, E, p + the 4 ping-pong partners of the state; the nine staged-only vectors are allocated
+    on first access (a 16384² block: 23.6 GB instead of 43; config 5's 32768² global grid on one GPU: 95 GB instead of 172)."""
+    n = 16392 * 16392 * 8
+    assert armon_amd.memory_required((16384, 16384), 4) == 11 * n
+    assert armon_amd.memory_required((16384, 16384), 4, transient=True) == 19 * n        # + the 8 spares of the placement search
+    assert armon_amd.memory_required((16384, 16384), 4, fused=False) == 16 * n
+    assert armon_amd.memory_required((100, 100), 4, data_type="float32", transient=True) == 13 * 108 * 108 * 4   # + c, g in cycle 0
 
 
 # ---- text I/O in the reference's format (ref src/io.jl) -----------------------------------------------------
