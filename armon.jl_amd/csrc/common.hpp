@@ -11,6 +11,7 @@
 
 #include "../../include/armon_hip.h"
 
+struct armon_graph;
 struct armon_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -37,6 +38,7 @@ struct armon_ctx {
     int seg_lag = -1, seg_cols = -1, seg_value = 0;
     // graphs captured on this context bake the address of `partials` in: it must not move while one is alive
     int live_graphs = 0;
+    armon_graph* graphs = nullptr;   // the live ones (intrusive list): a context destroyed first disowns them, see context.hip
     bool capturing = false;
 };
 
@@ -96,5 +98,6 @@ inline void range_grid(const armon_range& r, int cells_per_thread, dim3& grid, d
 }
 
 int ensure_partials(armon_ctx* ctx, size_t n);
+void disown_graphs(armon_ctx* ctx);      // dt_state.hip
 
 }  // namespace armon

@@ -144,6 +144,7 @@ int armon_hip_destroy(armon_ctx* ctx)
     if (!ctx) return ARMON_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    disown_graphs(ctx);              // graphs still alive lose their executables here (their handles stay valid to destroy)
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->scalars) (void)hipFree(ctx->scalars);
     if (ctx->host_scalars) (void)hipHostFree(ctx->host_scalars);

@@ -17,8 +17,28 @@ using namespace armon;
 struct armon_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    armon_ctx* ctx = nullptr;        // the context whose scratch the captured kernels point into
+    armon_ctx* ctx = nullptr;        // the context whose scratch the captured kernels point into (NULL once it is gone)
+    armon_graph* next = nullptr;     // the context's list of live graphs
 };
+
+// A context destroyed BEFORE its graphs (finalizers of a garbage-collected host run in any order): the executable graphs go
+// with it — their kernels point into its scratch —, the handles the host still holds become empty shells that
+// armon_hip_graph_launch refuses and armon_hip_graph_destroy frees without touching the context.
+void armon::disown_graphs(armon_ctx* ctx)
+{
+    for (armon_graph* g = ctx->graphs; g;) {
+        armon_graph* next = g->next;
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        g->exec = nullptr;
+        g->graph = nullptr;
+        g->ctx = nullptr;
+        g->next = nullptr;
+        g = next;
+    }
+    ctx->graphs = nullptr;
+    ctx->live_graphs = 0;
+}
 
 namespace {
 
@@ -88,6 +108,8 @@ int armon_hip_graph_end(armon_ctx* ctx, armon_graph** out)
     g->graph = graph;
     g->exec = exec;
     g->ctx = ctx;
+    g->next = ctx->graphs;
+    ctx->graphs = g;
     ctx->live_graphs++;
     *out = g;
     return ARMON_OK;
@@ -95,7 +117,8 @@ int armon_hip_graph_end(armon_ctx* ctx, armon_graph** out)
 
 int armon_hip_graph_launch(armon_ctx* ctx, armon_graph* g)
 {
-    ARMON_REQUIRE(ctx && g && g->exec, "NULL argument");
+    ARMON_REQUIRE(ctx && g, "NULL argument");
+    ARMON_REQUIRE(g->exec && g->ctx == ctx, "this graph was captured on another context, or its context has been destroyed");
     ARMON_HIP_TRY(hipGraphLaunch(g->exec, ctx->stream));
     return ARMON_OK;
 }
@@ -103,7 +126,14 @@ int armon_hip_graph_launch(armon_ctx* ctx, armon_graph* g)
 int armon_hip_graph_destroy(armon_graph* g)
 {
     if (!g) return ARMON_OK;
-    if (g->ctx && g->ctx->live_graphs > 0) g->ctx->live_graphs--;
+    if (g->ctx) {
+        for (armon_graph** p = &g->ctx->graphs; *p; p = &(*p)->next)
+            if (*p == g) {
+                *p = g->next;
+                break;
+            }
+        if (g->ctx->live_graphs > 0) g->ctx->live_graphs--;
+    }
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;

@@ -1148,8 +1148,14 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     // being fetched from the fabric by two. With one strip per wave that is the whole over-fetch of the sweep: 18.90 ->
     // 17.3 GB per launch by counters at 16384² (1.10x -> 1.01x the algorithmic bytes), time equal to 1.5 % better
     // (profiles/r04_ab_x_xcd.txt). fp64 only: fp32 shares its lines inside a workgroup instead (x_wg_along_x below).
+    // The order assumes what the part does in its default mode: 8 XCDs of 32 CUs, workgroups dealt round-robin. A device
+    // that shows another CU count (a partitioned MI355X: CPX / DPX modes) has fewer XCDs per agent, the map would only
+    // scramble rows there: it is switched off. The workgroup shape is decided first (a block with more than 65535 rows cannot
+    // take the along-x shape and falls back to one strip of 4 rows, which the remap then serves); the explicit knob wins.
     const bool want_along_x = ctx->tune_x_rows == 2 || (ctx->tune_x_rows == 0 && sizeof(real) == 4);
-    a.xcd_remap = ctx->tune_x_xcd < 0 ? (sizeof(real) == 8 && !want_along_x) : ctx->tune_x_xcd;
+    const bool along_x = X && want_along_x && d->ny <= 65535 && ctx->tune_x_xcd <= 0;
+    const bool eight_xcds = ctx->n_cu == 256;
+    a.xcd_remap = (ctx->tune_x_xcd < 0 ? sizeof(real) == 8 : ctx->tune_x_xcd != 0) && !along_x && eight_xcds;
     // origins row by row when one origin cannot align every row (the one-strip-per-wave form only; the A/B forms keep one)
     a.x_row_align = 0;
 #ifndef ARMON_XS_MULTI
@@ -1164,7 +1170,7 @@ extern "C" int ARMON_SWEEP_FN(armon_ctx* ctx, const ARMON_SWEEP_DESC* d)
     // workgroup shape of the X sweep (profiles/r03_ab_x_workgroup_shape.txt): 4 consecutive strips of one row pay for fp32
     // (1.54 -> 1.43 ms at 16384²: a 512-B strip shares a quarter of its 128-B lines with its neighbours) and not for fp64
     // (equal at 16384² and 4096 x 8192, +3 % at 8192²), which keeps one strip of 4 rows. ARMON_X_ROWS: 1 / 2 force a shape.
-    a.x_wg_along_x = (X && want_along_x && d->ny <= 65535 && !a.xcd_remap) ? 1 : 0;              // grid.y carries the rows
+    a.x_wg_along_x = along_x ? 1 : 0;                                                            // grid.y carries the rows
     a.partials = nullptr;
     if (track) {
         int rc = ensure_partials(ctx, (size_t)(2 * max_blocks(a)));

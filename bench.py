@@ -223,6 +223,14 @@ def slowest_rank(placement):
     return max(known, key=lambda pl: pl["chosen_vs_group_best"])["rank"] if known else None
 
 
+def lines_check(test, rho):
+    """For the test cases that vary along one axis only: (every row / column of this tile's density identical and finite,
+    the waves have left the initial two states on this tile)."""
+    import numpy as np
+    line = rho[:, 0:1] if test == "Sod_y" else rho[0:1]
+    return (bool(np.isfinite(rho).all() and np.array_equal(rho, np.broadcast_to(line, rho.shape))), bool(np.unique(line).size > 2))
+
+
 def placement_rate(placement, cells):
     """ms per Mcell of the chosen draw (tiles of one grid may differ in size), None when the tile was not placed."""
     if not placement or not placement.get("chosen_ms"):
@@ -396,12 +404,14 @@ def run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live
     import numpy as np
     mass1, energy1 = conservation_vars(params, grid)
     self_check = {"mass_drift": abs(mass1 - mass0) / abs(mass0), "energy_drift": abs(energy1 - energy0) / abs(energy0)}
-    if rank == 0 and args.test in ("Sod", "Sod_y", "Bizarrium"):
-        rho = grid.real_view(grid.data["rho"].to_host())
-        line = rho[:, 0:1] if args.test == "Sod_y" else rho[0:1]
-        self_check["lines_identical"] = bool(np.isfinite(rho).all() and np.array_equal(rho, np.broadcast_to(line, rho.shape)))
-        self_check["moved"] = bool(np.unique(line).size > 2)          # the waves have left the initial two states
-        del rho
+    if args.test in ("Sod", "Sod_y", "Bizarrium"):
+        ident, moved = lines_check(args.test, grid.real_view(grid.data["rho"].to_host()))
+        if dist is not None:                 # every rank's tile: identical lines everywhere, the waves moved somewhere
+            import torch
+            t = torch.tensor([float(ident), -float(moved)], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ident, moved = bool(t[0].item()), bool(-t[1].item())
+        self_check["lines_identical"], self_check["moved"] = ident, moved
 
     # Practical ceiling on THIS device: the same bytes (4 arrays read + 4 written) as a plain copy, no arithmetic.
     copy_gbps = None
@@ -523,12 +533,9 @@ def run_peer_workload(args, n_dev, P, N_global, device_ids, primary=True, live_t
         mass1, energy1 = group.conservation_vars()
         self_check = {"mass_drift": abs(mass1 - mass0) / abs(mass0), "energy_drift": abs(energy1 - energy0) / abs(energy0)}
         if args.test in ("Sod", "Sod_y", "Bizarrium"):
-            g0 = group.grids[0]
-            rho = g0.real_view(g0.data["rho"].to_host())
-            line = rho[:, 0:1] if args.test == "Sod_y" else rho[0:1]
-            self_check["lines_identical"] = bool(np.isfinite(rho).all() and np.array_equal(rho, np.broadcast_to(line, rho.shape)))
-            self_check["moved"] = bool(np.unique(line).size > 2)
-            del rho
+            checks = [lines_check(args.test, g.real_view(g.data["rho"].to_host())) for g in group.grids]
+            self_check["lines_identical"] = all(c[0] for c in checks)
+            self_check["moved"] = any(c[1] for c in checks)
         copy_gbps = None
         g0 = group.grids[0]
         if primary and g0.alt is not None:

@@ -358,7 +358,9 @@ ARMON_API int armon_hip_dt_state_step_f32(armon_ctx*, armon_dt_state* state_dev,
  * Invalidation rule: the captured kernels hold the address of the context's reduction scratch, so while a graph of a
  * context is alive that scratch cannot grow — a launch on the same context that needs more of it (a larger block, a
  * first dtCFL) FAILS with ARMON_ERR_INVALID_ARG instead of moving it; run such launches before capturing, or destroy the
- * graph first. A graph must be destroyed before its context. */
+ * graph first. A graph should be destroyed before its context; the other order is safe (finalizers of a garbage-collected
+ * host): armon_hip_destroy disowns the context's live graphs — their handles can then only be passed to
+ * armon_hip_graph_destroy, armon_hip_graph_launch refuses them. */
 typedef struct armon_graph armon_graph;
 ARMON_API int armon_hip_graph_begin(armon_ctx*);
 ARMON_API int armon_hip_graph_end(armon_ctx*, armon_graph** graph);

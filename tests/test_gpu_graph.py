@@ -200,6 +200,32 @@ def test_graph_capture_guards():
     gc.collect()
 
 
+def test_a_context_destroyed_before_its_graph_disowns_it():
+    """The wrong order (a garbage-collected host's finalizers): destroying the context first must not leave the graph with a
+    dangling back pointer — its handle stays valid for armon_hip_graph_destroy and is refused everywhere else."""
+    import ctypes as C
+    import armon_amd
+    from armon_amd import _lib
+    L = armon_amd.lib()
+    ctx, other = C.c_void_p(), C.c_void_p()
+    _lib.check(L.armon_hip_init(0, None, C.byref(ctx)))
+    _lib.check(L.armon_hip_init(0, None, C.byref(other)))
+    graphs = []
+    for _ in range(3):
+        _lib.check(L.armon_hip_graph_begin(ctx))
+        # (an empty capture is a valid graph)
+        g = C.c_void_p()
+        _lib.check(L.armon_hip_graph_end(ctx, C.byref(g)))
+        graphs.append(g)
+    assert L.armon_hip_graph_launch(other, graphs[0]) != 0 and b"another context" in L.armon_hip_last_error()
+    _lib.check(L.armon_hip_graph_destroy(graphs.pop(1)))          # the middle one, the right way round
+    _lib.check(L.armon_hip_destroy(ctx))                          # … then the context, with two graphs alive
+    assert L.armon_hip_graph_launch(other, graphs[0]) != 0 and b"has been destroyed" in L.armon_hip_last_error()
+    for g in graphs:
+        _lib.check(L.armon_hip_graph_destroy(g))                  # no write through the dead context
+    _lib.check(L.armon_hip_destroy(other))
+
+
 def test_dt_state_is_refused_by_the_kernels_that_ignore_it():
     """The LDS X march and the whole-cycle kernels of the A/B build never read armon_dt_state: a descriptor that carries
     one is an error there, not a silently wrong time step."""

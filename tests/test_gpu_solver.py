@@ -682,7 +682,8 @@ def test_vectors_that_do_not_start_on_a_sector(N, dtype, offset):
                 a.device, a.n, a.dtype, a.nbytes = big.device, v.n, v.dtype, v.nbytes
                 a.ptr, a.owner = big.ptr + offset, big
                 return a
-            grid.data = {f: shifted_view(v) for f, v in grid.data.items()}
+            for f, v in list(grid.data.items()):          # in place: grid.data also creates c, g when cycle 0 asks for them
+                grid.data[f] = shifted_view(v)
             grid.alt = {f: shifted_view(v) for f, v in grid.alt.items()}
         init_test(params, grid)
         _t, dt, cycles, _, _ = time_loop(params, grid)
