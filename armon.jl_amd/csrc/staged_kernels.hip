@@ -132,7 +132,12 @@ constexpr int kGadValid = 62;
 #define ARMON_GAD_ALIGNED 1      // x forms (GAD, second-order advection): 1 = waves that store whole sectors (56 of 64 lanes in fp64), 0 = 62 / 60
 #endif
 #ifndef ARMON_GAD_ROWS
-#define ARMON_GAD_ROWS 64        // rows per thread of the y form (tuning macro)
+// rows per thread of the y form (tuning macro). SHORT walks: 8 rows cost 3 extra row loads per 8 — served by the L2, the rows
+// were just read by the workgroup below — and put 8 x as many workgroups of a column in flight, so that the device streams a
+// narrow window of rows instead of 30 distant fronts: 2.58-2.71 -> 2.25-2.33 ms at 16384² (4, 6, 12, 16, 32 rows: 2.41, 2.34,
+// 2.28, 2.44, 2.66; a chunk-major launch with XCD-stable column blocks: no further gain; profiles/r05_staged_y_chunks.txt).
+// Round 3 had only tried LONGER walks (64 -> 256 rows: equal).
+#define ARMON_GAD_ROWS 8
 #endif
 constexpr int kGadRows = ARMON_GAD_ROWS;
 #ifndef ARMON_GAD_AHEAD
@@ -392,7 +397,10 @@ k_advection_second_order(armon_range r, int64_t s, T dx, T dt,
 //  * sweep along y: lane ↔ column, kAdvRows rows per thread with rolling windows — 5 loads per row.
 // No cell outside the reference's own stencil (uˢ @ is-2s..is+2s; ρ,u,v,E @ is-2s..is+s) is read.
 constexpr int kAdvValid = 60;
-constexpr int kAdvRows = 64;
+#ifndef ARMON_ADV_ROWS
+#define ARMON_ADV_ROWS 8         // rows per thread of the y form (tuning macro): as ARMON_GAD_ROWS — 3.31-3.47 -> 3.24-3.31 ms at 16384²
+#endif
+constexpr int kAdvRows = ARMON_ADV_ROWS;
 
 template <typename T> struct adv_cell { T rho, qu, qv, qE; };
 

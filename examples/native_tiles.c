@@ -2,7 +2,8 @@
  * of tiles in ONE process (armon_hip_mgpu_init; every tile on device 0 unless device ids are given), per sweep
  *   armon_hip_halo_exchange_start -> interior of the fused sweep on the compute stream, while on the tile's transfer
  *   stream: armon_hip_halo_exchange_finish_edge -> boundary strips (armon_hip_mgpu_edge_ctx) -> armon_hip_mgpu_edge_join,
- * the dt/CFL minimum reduced over the tiles on the device (armon_hip_dt_allreduce) and read back one cycle late — the
+ * the dt/CFL minimum reduced over the tiles on the device (armon_hip_dt_allreduce) and read back one cycle late — or, with
+ * a 5th argument "cycle", all of that per cycle by ONE call: armon_hip_mgpu_cycle — the
  * reference's cycle (ref src/solver.jl:288-320) with its MPI exchange (ref src/halo_exchange.jl:229-354) and
  * MPI_Iallreduce (ref src/solver_state.jl:89-111) replaced by the library's own entry points. No host synchronisation
  * inside a cycle. Prints the global mass and energy: they must equal examples/native_cycle's for the same grid and
@@ -35,7 +36,7 @@ typedef struct {
 
 /* one fused sweep of a sub-range [lo, hi) of the sweep axis (hi == 0: the whole tile), launched on `ctx`; dt_out: where
  * the CFL step of the cells it produced goes (NULL: not wanted) */
-static int sweep(tile* t, armon_ctx* ctx, int axis, double dt, double dx, int64_t lo, int64_t hi, double* dt_out)
+static armon_sweep_desc sweep_desc(const tile* t, int axis, double dt, double dx, int64_t lo, int64_t hi, double* dt_out)
 {
     armon_sweep_desc d;
     memset(&d, 0, sizeof d);
@@ -50,6 +51,12 @@ static int sweep(tile* t, armon_ctx* ctx, int axis, double dt, double dx, int64_
     d.rho_out = t->a[0]; d.u_out = t->a[1]; d.v_out = t->a[2]; d.E_out = t->a[3];
     d.out_lo = lo; d.out_hi = hi;
     if (dt_out) { d.dt_cfl_out = dt_out; d.cfl_dx = d.cfl_dy = dx; }
+    return d;
+}
+
+static int sweep(tile* t, armon_ctx* ctx, int axis, double dt, double dx, int64_t lo, int64_t hi, double* dt_out)
+{
+    const armon_sweep_desc d = sweep_desc(t, axis, dt, dx, lo, hi, dt_out);
     return armon_hip_sweep(ctx, &d);
 }
 
@@ -58,6 +65,9 @@ int main(int argc, char** argv)
     const int64_t n = argc > 1 ? atoll(argv[1]) : 1024;
     const int px = argc > 2 ? atoi(argv[2]) : 2, py = argc > 3 ? atoi(argv[3]) : 2;
     const int cycles = argc > 4 ? atoi(argv[4]) : 20;
+    /* "cycle": every cycle by ONE call (armon_hip_mgpu_cycle: the sequence below enqueued by the library, one host thread
+     * per tile, the next CFL step reduced and read back on the transfer streams) instead of call by call */
+    const int one_call = argc > 5 && !strcmp(argv[5], "cycle");
     const int nt = px * py;
     if (nt < 1 || nt > MAX_TILES || n / px < 2 * LAG + 1 || n / py < 2 * LAG + 1) { fprintf(stderr, "bad tile grid\n"); return 1; }
     const double dx = 1.0 / (double)n, cfl = 0.95;
@@ -109,7 +119,30 @@ int main(int argc, char** argv)
     double* dt_host;
     CHECK(armon_hip_malloc_host(T[0].ctx, 2 * sizeof(double), (void**)&dt_host));
 
-    for (int c = 0; c < cycles; c++) {
+    for (int c = 0; c < cycles && one_call; c++) {
+        armon_cycle_plan plan;
+        static armon_tile_cycle tc[MAX_TILES];
+        memset(&plan, 0, sizeof plan);
+        plan.n_sweeps = 2; plan.emit_dt = 1; plan.overlap = 1;
+        plan.axis[0] = ARMON_AXIS_X; plan.axis[1] = ARMON_AXIS_Y; plan.dt[0] = plan.dt[1] = dt;
+        plan.next_axis = c + 1 < cycles ? ARMON_AXIS_X : -1;    /* the next cycle's first exchange is posted ahead */
+        plan.event_slot = -1;
+        plan.dt_host = &dt_host[c & 1]; plan.dt_event_slot = c & 1;             /* an event of tile 0's EDGE context */
+        for (int r = 0; r < nt; r++) {                          /* full sweeps from the set that holds the state now */
+            tc[r].x = sweep_desc(&T[r], ARMON_AXIS_X, 0., dx, 0, 0, T[r].dt_dev);
+            tc[r].y = sweep_desc(&T[r], ARMON_AXIS_Y, 0., dx, 0, 0, T[r].dt_dev);
+        }
+        CHECK(armon_hip_mgpu_cycle(group, &plan, tc));          /* two sweeps: the state is back in the same set */
+        if (c > 0) {
+            CHECK(armon_hip_event_sync(T[0].edge, (c - 1) & 1));
+            const double l = dt_host[(c - 1) & 1];
+            if (!(l > 0.) || !isfinite(l)) { fprintf(stderr, "invalid time step at cycle %d\n", c); return 2; }
+            next_dt = fmin(cfl * l, 1.05 * dt);
+        }
+        dt = next_dt;
+    }
+    if (one_call) CHECK(armon_hip_mgpu_sync(group));            /* compute AND transfer streams */
+    for (int c = 0; c < cycles && !one_call; c++) {
         for (int axis = ARMON_AXIS_X; axis <= ARMON_AXIS_Y; axis++) {
             const int last = axis == ARMON_AXIS_Y;
             for (int r = 0; r < nt; r++) {                     /* what every tile exchanges: its current rho,u,v,E */

@@ -92,7 +92,8 @@ function create_device(::Val{:HIP_native})
 end
 
 function init_backend(params::ArmonParameters, dev::HIPNative;
-                      armon_hip_lib = "libarmon_hip.so", device_id = 0, fused_sweep = true, exact_arithmetic = false, options...)
+                      armon_hip_lib = "libarmon_hip.so", device_id = 0, fused_sweep = true, exact_arithmetic = false,
+                      native_cycle = true, options...)
     LIB[] = Libdl.dlopen(armon_hip_lib)
     empty!(SYMS)
     @assert ccall(fn(:armon_hip_flt_size), Cint, ()) == 8      # ref ext/ArmonKokkos.jl:122-139
@@ -100,7 +101,7 @@ function init_backend(params::ArmonParameters, dev::HIPNative;
     ctx = Ref{Ptr{Cvoid}}()
     check(ccall(fn(:armon_hip_init), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), device_id, C_NULL, ctx))
     dev.ctx, dev.device_id = ctx[], device_id
-    params.backend_options = (; fused_sweep, exact_arithmetic)
+    params.backend_options = (; fused_sweep, exact_arithmetic, native_cycle)
     return options
 end
 
@@ -265,17 +266,15 @@ function fused_state(p::HP{T}, grid::BlockGrid) where T
     end
 end
 
-"One directional sweep of one block as ONE launch (armon_hip_sweep), then exchange the roles of the two state sets."
-function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}; emit_p::Bool, emit_dt::Bool,
-                      out::NTuple{2, Int} = (0, 0),            # cells [out[1], out[2]) of the sweep axis; (0, 0) = all
-                      ctx::Ptr{Cvoid} = p.device.ctx,          # or the tile's edge context (transfer stream)
-                      dt_out::Ptr{T} = pointer(fs.dt_dev), swap::Bool = true) where T
+"The armon_sweep_desc of the sweep `state` is set up for (update_solver_state!): current state of `blk` → its ping-pong partners."
+function sweep_desc(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}; emit_p::Bool, emit_dt::Bool,
+                    out::NTuple{2, Int} = (0, 0), dt_out::Ptr{T} = pointer(fs.dt_dev)) where T
     d = block_device_data(blk); alt = fs.alt[blk]
     nx, ny = real_block_size(blk.size)
     lo, hi = first_side(state.axis), last_side(state.axis)
     (ufl, vfl) = boundary_condition(state.test_case, lo); (ufh, vfh) = boundary_condition(state.test_case, hi)
     Δ = p.domain_size ./ p.global_grid
-    desc = Ref(SweepDesc{T}(
+    SweepDesc{T}(
         Int(state.axis) - 1, scheme_tag(state.riemann_scheme), limiter_tag(state.riemann_limiter),
         projection_tag(state.projection_scheme), eos_tag(state.test_case), ghosts(blk.size),
         !has_neighbour(p, lo), !has_neighbour(p, hi), p.backend_options.exact_arithmetic, 0,
@@ -283,7 +282,16 @@ function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::Fus
         pointer(d.ρ), pointer(d.u), pointer(d.v), pointer(d.E),
         pointer(alt[1]), pointer(alt[2]), pointer(alt[3]), pointer(alt[4]),
         emit_p ? pointer(d.p) : Ptr{T}(C_NULL), Ptr{T}(C_NULL),
-        emit_dt ? dt_out : Ptr{T}(C_NULL), Δ[1], Δ[2], out[1], out[2], 0, 0, C_NULL))
+        emit_dt ? dt_out : Ptr{T}(C_NULL), Δ[1], Δ[2], out[1], out[2], 0, 0, C_NULL)
+end
+
+"One directional sweep of one block as ONE launch (armon_hip_sweep), then exchange the roles of the two state sets."
+function fused_sweep!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}; emit_p::Bool, emit_dt::Bool,
+                      out::NTuple{2, Int} = (0, 0),            # cells [out[1], out[2]) of the sweep axis; (0, 0) = all
+                      ctx::Ptr{Cvoid} = p.device.ctx,          # or the tile's edge context (transfer stream)
+                      dt_out::Ptr{T} = pointer(fs.dt_dev), swap::Bool = true) where T
+    d = block_device_data(blk); alt = fs.alt[blk]
+    desc = Ref(sweep_desc(p, state, blk, fs; emit_p, emit_dt, out, dt_out))
     GC.@preserve d alt check(ccall(fn(:armon_hip_sweep, T), Cint, (Ptr{Cvoid}, Ptr{SweepDesc{T}}), ctx, desc))
     swap && swap_state!(blk, fs)
 end
@@ -339,6 +347,54 @@ function fused_sweep_mpi!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs:
     swap_state!(blk, fs)
 end
 
+# The whole cycle of this rank's tile in ONE library call (armon_hip_mgpu_cycle, include/armon_hip.h): the exchanges along each
+# sweep's axis, the interior while the faces travel, unpack + strips on the transfer stream, the all-reduce of the next CFL
+# step and its read-back into the pinned slot — everything fused_sweep_mpi! / dt_allreduce! / the read-back below do call by
+# call, enqueued natively (≈ 0.1 ms of host time per cycle instead of ≈ 0.2–0.6), with the exchange of the NEXT cycle's
+# first sweep posted ahead. `false` when the library refuses nothing; the caller keeps the call-by-call path as its fallback.
+struct CyclePlan         # == armon_cycle_plan
+    n_sweeps::Cint; emit_p::Cint; emit_dt::Cint; overlap::Cint
+    axis::NTuple{4, Cint}; dt::NTuple{4, Float64}
+    next_axis::Cint; event_slot::Cint
+    event_ctx::Ptr{Cvoid}; dt_host::Ptr{Cvoid}; dt_event_slot::Cint; reserved::Cint
+end
+struct TileCycle{T}      # == armon_tile_cycle / armon_tile_cycle_f32
+    x::SweepDesc{T}; y::SweepDesc{T}
+end
+
+function native_cycle!(p::HP{T}, state::SolverState, blk::LocalTaskBlock, fs::FusedState{T}, will_end::Bool) where T
+    g = rank_group(p)
+    gdt = state.global_dt
+    sweeps = collect(split_axes(state))
+    axes = zeros(Cint, 4); dts = zeros(Float64, 4)
+    descs = Dict{Axis.T, SweepDesc{T}}()
+    for (k, (axis, dt_factor)) in enumerate(sweeps)
+        update_solver_state!(p, state, axis, dt_factor)          # dx, dt = current_dt·factor, steps_ranges of that axis
+        axes[k] = Int(axis) - 1; dts[k] = state.dt
+        descs[axis] = sweep_desc(p, state, blk, fs; emit_p = true, emit_dt = !p.cst_dt)
+    end
+    for axis in (Axis.X, Axis.Y)                                  # a splitting that skips an axis: its descriptor is never read
+        haskey(descs, axis) || (descs[axis] = descs[first(keys(descs))])
+    end
+    next_first = Int(first(first(split_axes(state.splitting, T, gdt.cycle + 1)))) - 1     # ref src/axis_splitting.jl:22
+    slot = gdt.cycle & 1
+    plan = Ref(CyclePlan(length(sweeps), will_end, !p.cst_dt, 1, Tuple(axes), Tuple(dts), will_end ? -1 : next_first, -1,
+        C_NULL, p.cst_dt ? C_NULL : Ptr{Cvoid}(fs.dt_host + slot * sizeof(T)), p.cst_dt ? -1 : DT_EVENT_SLOT + slot, 0))
+    tile = Ref(TileCycle{T}(descs[Axis.X], descs[Axis.Y]))
+    d = block_device_data(blk); alt = fs.alt[blk]
+    GC.@preserve d alt check(ccall(fn(:armon_hip_mgpu_cycle, T), Cint, (Ptr{Cvoid}, Ptr{CyclePlan}, Ptr{TileCycle{T}}), g.handle, plan, tile))
+    isodd(length(sweeps)) && swap_state!(blk, fs)
+    p.cst_dt && return false
+    push!(fs.posted, gdt.cycle)
+    if gdt.cycle > 0                                              # the read-back the previous cycle posted, on the EDGE context
+        prev = gdt.cycle - 1
+        check(ccall(fn(:armon_hip_event_sync), Cint, (Ptr{Cvoid}, Cint), edge_context(g, 0), DT_EVENT_SLOT + (prev & 1)))
+        delete!(fs.posted, prev)
+        contribute_to_dt!(p, gdt, unsafe_load(fs.dt_host, (prev & 1) + 1); all_blocks = true)
+    end
+    return false
+end
+
 function solver_cycle(p::HP{T}, grid::BlockGrid) where T
     # per-step dumps/comparisons need the intermediate arrays of the staged kernels (then MPI runs keep the reference's
     # exchange between them, on gpu_aware buffers); otherwise MPI runs take the library's RCCL group, see above
@@ -356,6 +412,9 @@ function solver_cycle(p::HP{T}, grid::BlockGrid) where T
         state.dt = gdt.current_dt                         # known since the previous cycle (one-cycle lag)
     end
     will_end = gdt.cycle + 1 ≥ p.maxcycle || gdt.time + gdt.current_dt ≥ p.maxtime    # time_loop's exit test (src/solver.jl:350)
+    if mpi && p.backend_options.native_cycle                  # default: the library enqueues the whole cycle
+        return native_cycle!(p, state, first(all_blocks(grid)), fs, will_end)
+    end
     sweeps = collect(split_axes(state))
     for (k, (axis, dt_factor)) in enumerate(sweeps)
         update_solver_state!(p, state, axis, dt_factor)

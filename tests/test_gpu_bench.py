@@ -120,3 +120,17 @@ def test_a_slow_rank_redraws_its_placement():
     pl = {p["rank"]: p for p in d["config"]["hbm_placement"]}
     assert "redraw" in pl[1] and pl[1]["tries"] > pl[1]["max_tries"]      # (rank 0 may redraw too: two ranks share this GPU, timings are noisy)
     assert d["config"]["slowest_rank"] in (0, 1) and all("chosen_vs_group_best" in p for p in pl.values())
+
+
+def test_one_rank_over_real_rccl_runs_both_workloads_through_the_native_cycle():
+    """What one GPU can execute of the real N > 1 rank path: torch.distributed over RCCL (nccl backend) with ONE rank, the
+    library's own RCCL group (two communicators, the all-reduce of the next CFL step on the transfer stream), whole cycles
+    through armon_hip_mgpu_cycle, the transports' self-check — and the SECOND workload in the same process, which tears the
+    library's communicators down and builds them again (ARMON_BENCH_FORCE_DIST / ARMON_BENCH_FORCE_SECOND)."""
+    d = run_line([sys.executable, BENCH, "--cells", "1024", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                 env={"ARMON_BENCH_FORCE_DIST": "1", "ARMON_BENCH_FORCE_SECOND": "1"})
+    assert d["n_gpus"] == 1 and d["config"]["halo_exchange_downgraded"] is False, d["config"]["halo_exchange_error"]
+    assert d["config"]["halo_exchange"].startswith("native (armon_hip_halo_exchange over RCCL")
+    assert d["weak"]["value"] > 0 and d["weak"]["halo_exchange_downgraded"] is False
+    assert d["self_check"]["mass_drift"] <= 1e-12 and d["weak"]["self_check"]["lines_identical"] is True
+    assert set(d["roofline"]["per_kernel_ms"]) == {"sweep_x", "sweep_y"} and d["roofline"]["launches_timed"] == 6

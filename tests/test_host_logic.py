@@ -318,12 +318,12 @@ def test_bench_launches_its_own_ranks_and_reports_failure_with_a_status():
 
 
 def test_design_md_quotes_what_the_committed_profiles_say():
-    """DESIGN.md's measured tables sit between `evidence` markers and are injected from profiles/r04_* by
+    """DESIGN.md's measured tables sit between `evidence` markers and are injected from profiles/r05_* by
     tools/evidence_table.py: a number typed by hand, or a profile re-collected without re-injecting, fails here."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "4", "--check", os.path.join(ROOT, "DESIGN.md")],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "5", "--check", os.path.join(ROOT, "DESIGN.md")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
-    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "4"], capture_output=True, text=True)
-    assert gen.returncode == 0 and gen.stdout == open(os.path.join(ROOT, "profiles", "r04_evidence.md")).read()
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "5"], capture_output=True, text=True)
+    assert gen.returncode == 0 and gen.stdout == open(os.path.join(ROOT, "profiles", "r05_evidence.md")).read()

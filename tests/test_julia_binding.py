@@ -76,6 +76,8 @@ def jl_kind(t, real_width):
         return ("float", real_width)
     if t == "CRange":
         return ("struct", C.sizeof(_lib.Range))
+    if t == "SweepDesc{T}":
+        return ("struct", C.sizeof(_lib.SweepDesc))
     if t == "Cstring" or t.startswith("Ptr{") or t.startswith("Ref{"):
         return ("ptr", 8)
     raise AssertionError(f"unmapped Julia type {t!r}")
@@ -111,7 +113,7 @@ def test_the_binding_calls_the_abi_it_claims():
                  "dtCFL", "conservation_vars", "init_test", "sweep", "tune_placement", "init", "sync", "malloc", "free",
                  "memcpy", "memcpy_async", "malloc_host", "event_record", "event_sync", "device_memory_info",
                  "mgpu_init", "mgpu_init_rank", "mgpu_unique_id", "halo_exchange_start", "halo_exchange_finish",
-                 "dt_allreduce"):
+                 "dt_allreduce", "mgpu_cycle"):
         assert "armon_hip_" + must in names, must
 
 
@@ -155,7 +157,8 @@ def ct_field_kind(t):
 
 
 @pytest.mark.parametrize("jl,ct,same_names", [("CRange", _lib.Range, True), ("SweepDesc", _lib.SweepDesc, True),
-                                              ("HaloDesc", _lib.HaloDesc, True), ("CBlockData", _lib.BlockDataPtrs, False)])
+                                              ("HaloDesc", _lib.HaloDesc, True), ("CBlockData", _lib.BlockDataPtrs, False),
+                                              ("CyclePlan", _lib.CyclePlan, True), ("TileCycle", _lib.TileCycle, True)])
 def test_struct_mirrors(jl, ct, same_names):
     fields = jl_struct(jl)
     assert len(fields) == len(ct._fields_), (jl, len(fields), len(ct._fields_))
@@ -251,7 +254,7 @@ def test_julia_file_is_structurally_sound():
     defined = set(re.findall(r"^\s*(?:function\s+)?([A-Za-z_][\w!]*)\s*(?:\{[^}]*\})?\(", src, re.M))
     for name in ("fused_sweep!", "fused_sweep_mpi!", "swap_state!", "rank_group", "sweep_lag", "fused_state", "unique_id",
                  "halo_exchange_start!", "halo_exchange_finish!", "halo_exchange_finish_edge!", "edge_context", "edge_dt",
-                 "edge_join!", "dt_allreduce!", "TileGroup", "HaloDesc", "check", "fn"):
+                 "edge_join!", "dt_allreduce!", "TileGroup", "HaloDesc", "check", "fn", "sweep_desc", "native_cycle!"):
         assert name in defined, f"{name} is called but never defined"
 
 

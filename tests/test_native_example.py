@@ -53,14 +53,16 @@ def test_native_example_matches_the_python_host(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["calls", "cycle"])
 @pytest.mark.parametrize("n,px,py", [(640, 2, 2), (517, 3, 1), (400, 1, 2)])
-def test_native_tiles_example_matches_the_python_tile_group(tmp_path, n, px, py):
+def test_native_tiles_example_matches_the_python_tile_group(tmp_path, n, px, py, mode):
     """examples/native_tiles.c — the multi-GPU entry points (armon_hip_mgpu_init, halo_exchange_start/finish,
     dt_allreduce) driven from plain C, every tile on device 0 — ends on the same global mass and energy, bit for bit, as
-    multi_tile.TileGroup on the same tile grid (same kernels, same exchange, same dt rule, same order of the sums)."""
+    multi_tile.TileGroup on the same tile grid (same kernels, same exchange, same dt rule, same order of the sums).
+    mode "cycle": the same run with every cycle enqueued by ONE armon_hip_mgpu_cycle call."""
     from armon_amd.multi_tile import TileGroup
     cycles = 30
-    out = subprocess.run([build_example(tmp_path, "native_tiles"), str(n), str(px), str(py), str(cycles)], check=True,
+    out = subprocess.run([build_example(tmp_path, "native_tiles"), str(n), str(px), str(py), str(cycles), mode], check=True,
                          capture_output=True, text=True).stdout
     m = re.search(r"mass (\S+) -> (\S+), energy (\S+) -> (\S+)", out)
     assert m, out
