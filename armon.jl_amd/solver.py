@@ -119,14 +119,15 @@ class _Fields(dict):
 
     def __init__(self, grid, names):
         super().__init__()
-        self._grid = grid
+        import weakref
+        self._grid_ref = weakref.ref(grid)     # no reference cycle: a dropped grid must release its vectors at once (86 GB blocks follow each other in the tests)
         for f in names:
             self[f] = grid.params.device.empty(grid.size.n_cells, grid.params.data_type)
 
     def __missing__(self, key):
         if key not in FIELDS:
             raise KeyError(key)
-        grid = self._grid
+        grid = self._grid_ref()
         a = grid.params.device.zeros(grid.size.n_cells, grid.params.data_type)
         if key == "mask" and grid.initialised:
             g = grid.size.ghosts

@@ -801,6 +801,12 @@ def main():
             local_rank = 0
             dist.init_process_group("gloo")
         else:
+            # one GPU per rank: LOCAL_RANK-th of the devices this process can see — or the only one, when the launcher
+            # narrowed every rank's view to its own GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank)
+            visible = torch.cuda.device_count()
+            if visible < 1:
+                sys.exit(f"bench.py rank {rank}: no GPU visible")
+            local_rank = local_rank % visible
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -823,6 +829,14 @@ def main():
         #                                   the library's communicators down and building them again inside one process)
 
     device_ids = [0] * world_tiles if rehearsal else list(range(world_tiles))
+    if peer and not rehearsal:
+        import ctypes
+        import armon_amd
+        count = ctypes.c_int()
+        armon_amd.lib().armon_hip_device_count(ctypes.byref(count))
+        if count.value < world_tiles:
+            sys.exit(f"--transport peer --gpus {world_tiles}: this process sees {count.value} GPU(s) "
+                     "(ARMON_BENCH_REHEARSAL=1 puts every tile on device 0: a rehearsal, not a measurement)")
 
     def run(N_global, kind, primary):
         PHASE["name"] = f"{kind} workload {N_global[0]}x{N_global[1]}"

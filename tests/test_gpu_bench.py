@@ -47,8 +47,11 @@ def test_traffic_is_measured_for_the_line_by_default():
         pytest.skip("rocprofv3 not on PATH")
     d = run_line([sys.executable, BENCH, "--cells", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     ro = d["roofline"]
-    if "live measurement failed" in (ro["traffic_source"] or ""):
-        pytest.skip("counter passes not available on this box: " + ro["traffic_source"])     # the line says so itself; not a code error
+    src = ro["traffic_source"] or ""
+    if "live measurement failed" in src and ("rocprofv3 not found" in src or "ounters" in src and "unavailable" in src):
+        pytest.skip("counter passes not available on this box: " + src)
+    # any other failure of the live measurement is a regression of the counter path (the line carries the child's status
+    # and the tail of its stderr): it must fail here, not hide behind a skip
     assert ro["traffic_source"].startswith("measured for this line"), ro["traffic_source"]
     algorithmic = 64 * 2048 * 2048
     assert 0.98 * algorithmic <= ro["traffic"] <= 1.25 * algorithmic, ro["traffic"] / algorithmic

@@ -327,3 +327,42 @@ def test_design_md_quotes_what_the_committed_profiles_say():
     assert r.returncode == 0, r.stderr + r.stdout
     gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "evidence_table.py"), "5"], capture_output=True, text=True)
     assert gen.returncode == 0 and gen.stdout == open(os.path.join(ROOT, "profiles", "r05_evidence.md")).read()
+
+
+def test_bench_launcher_helpers_kill_by_process_group_and_find_the_line(tmp_path):
+    """bench.py's parent side without any GPU: a child that hangs is killed through ITS process group after the limit (and
+    the grandchild it started with it), a child's stdout is searched for the one JSON line whatever the libraries printed
+    around it, and the exit status travels."""
+    import importlib.util
+    import subprocess
+    import sys
+    import time
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    marker = tmp_path / "grandchild.pid"
+    hang = tmp_path / "hang.py"
+    hang.write_text("import subprocess, sys, time\n"
+                    f"p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(120)'])\n"
+                    f"open({str(marker)!r}, 'w').write(str(p.pid))\n"
+                    "print('banner on stdout', flush=True)\ntime.sleep(120)\n")
+    t0 = time.time()
+    rc, out = bench.run_child([sys.executable, str(hang)], dict(os.environ), timeout=3)
+    assert rc == -9 and time.time() - t0 < 30
+    pid = int(marker.read_text())
+    for _ in range(50):                                   # the grandchild went with the group
+        if subprocess.run(["ps", "-p", str(pid)], capture_output=True).returncode != 0:
+            break
+        time.sleep(0.1)
+    assert subprocess.run(["ps", "-p", str(pid), "-o", "stat="], capture_output=True, text=True).stdout.strip() in ("", "Z")
+    ok = tmp_path / "ok.py"
+    ok.write_text("import sys\nprint('RCCL version : x')\nprint('{\"not\": \"the line\"}')\n"
+                  "print('{\"metric\": \"m\", \"value\": 1.5}')\nprint('trailing noise')\nsys.exit(3)\n")
+    rc, out = bench.run_child([sys.executable, str(ok)], dict(os.environ), timeout=30)
+    assert rc == 3 and bench.last_json_line(out) == {"metric": "m", "value": 1.5}
+    assert bench.last_json_line("no json here\n") is None and bench.last_json_line("") is None
+    # placement bookkeeping of the N > 1 line
+    pl = bench.annotate_placements([{"rank": 0, "chosen_ms": 0.75, "tries": 12}, {"rank": 1, "tries": 0}, {"rank": 2, "chosen_ms": 0.80, "tries": 16}],
+                                   [33554432, 33554432, 33554432])
+    assert pl[0]["chosen_vs_group_best"] == 1.0 and round(pl[2]["chosen_vs_group_best"], 3) == 1.067 and "chosen_vs_group_best" not in pl[1]
+    assert bench.slowest_rank(pl) == 2 and bench.slowest_rank([{"rank": 0, "tries": 0}]) is None and bench.slowest_rank(None) is None
