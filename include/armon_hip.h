@@ -545,7 +545,11 @@ ARMON_API int armon_hip_dt_allreduce_f32(armon_mgpu*, float* const* dt_dev);
  *          *_in = the vectors that hold the state when the call is made and *_out = their partners (the same two sets in x
  *          and y); p_out / dt_cfl_out name where emit_p / emit_dt put their results; dt, bc_low / bc_high, out_lo / out_hi,
  *          dt_accumulate are set by the library (the sides from the group's topology). After the call the state is in the
- *          *_out set when n_sweeps is odd, in the *_in set when it is even. */
+ *          *_out set when n_sweeps is odd, in the *_in set when it is even.
+ * Environment knobs of a group, read when it is created (measurement tools; none changes a result bit): ARMON_MGPU_THREADS=0
+ * (no host threads), ARMON_MGPU_XFER_PRIORITY=normal|lowest (priority of the transfer streams; default lowest when a tile has
+ * its device to itself), ARMON_MGPU_PACK=compute (halo packs in front of the interior on the compute stream, as until round
+ * 4), ARMON_MGPU_TIMING=1 (host time of tile 0's steps inside the call, printed when the group is destroyed). */
 typedef struct {
     int32_t n_sweeps, emit_p, emit_dt, overlap;
     int32_t axis[4];             /* [0 .. n_sweeps) used */
