@@ -218,11 +218,16 @@ int make_tile_resources(tile_t& t, bool alone_on_device)
     // interiors (8 tiles on one device: 6.3 -> 6.7 ms). ARMON_MGPU_XFER_PRIORITY=normal / lowest overrides.
     {
         int least = 0, greatest = 0;
-        ARMON_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const char* v = getenv("ARMON_MGPU_XFER_PRIORITY");
-        const bool normal = v && *v ? !strcmp(v, "normal") : !alone_on_device;
+        bool normal = v && *v ? !strcmp(v, "normal") : !alone_on_device;
+        // (a runtime without stream priorities is not an error: the transfer stream is then an ordinary one)
+        if (!normal && (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+                        hipStreamCreateWithPriority(&t.xfer, hipStreamNonBlocking, least) != hipSuccess)) {
+            (void)hipGetLastError();
+            t.xfer = nullptr;
+            normal = true;
+        }
         if (normal) ARMON_HIP_TRY(hipStreamCreateWithFlags(&t.xfer, hipStreamNonBlocking));
-        else ARMON_HIP_TRY(hipStreamCreateWithPriority(&t.xfer, hipStreamNonBlocking, least));
     }
     for (int s = 0; s < kSides; s++) {
         ARMON_HIP_TRY(hipEventCreateWithFlags(&t.e_pack[s], hipEventDisableTiming));
