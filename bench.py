@@ -309,6 +309,10 @@ def run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live
         if torch_comm.stream_ordered or native_comm is not None:
 
             def probe(comm, stream_ordered, cycles=5):
+                try:
+                    drain_halo(grid)             # whatever a previous candidate left posted (it may have failed half-way)
+                except Exception:
+                    pass
                 grid.comm = comm
                 if comm is torch_comm:
                     comm.stream_ordered = stream_ordered
@@ -327,13 +331,17 @@ def run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live
             could_order = torch_comm.stream_ordered
             ref = probe(torch_comm, False)
             halo_mode, chosen = None, None
-            candidates = ([("native (armon_hip_halo_exchange over RCCL send/recv on a transfer stream, unpack and boundary "
-                            "strips on that stream too, armon_hip_dt_allreduce; device-ordered)", native_comm, True)]
-                          if native_comm else [])
+            # (the library's exchange twice: whole cycles enqueued by ONE call — armon_hip_mgpu_cycle, packs and the dt chain on
+            # the transfer stream — and, should that form misbehave on this machine, the same exchange driven call by call)
+            native_name = ("native (armon_hip_halo_exchange over RCCL send/recv on a transfer stream, unpack and boundary "
+                           "strips on that stream too, dt all-reduce by the library; device-ordered; ")
+            candidates = ([(native_name + "whole cycles enqueued by armon_hip_mgpu_cycle)", native_comm, True, True),
+                           (native_name + "driven call by call)", native_comm, True, False)] if native_comm else [])
             if could_order:
-                candidates.append(("torch.distributed RCCL, stream-ordered", torch_comm, True))
+                candidates.append(("torch.distributed RCCL, stream-ordered", torch_comm, True, False))
             failed = []
-            for name, comm, so in candidates:
+            for name, comm, so, one_call in candidates:
+                params.native_cycle = one_call
                 try:
                     same = 1.0 if probe(comm, so) == ref else 0.0
                     if same == 0.0:
@@ -343,15 +351,16 @@ def run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live
                     failed.append(f"{name.split(' ')[0]}: {type(e).__name__}")
                     halo_errors.append(f"{name.split(' ')[0]}: {type(e).__name__}: {str(e)[:300]}")
                 if allreduce_min(params, same) == 1.0:
-                    halo_mode, chosen = name + " — self-check against the host-synchronised protocol passed", (comm, so)
+                    halo_mode, chosen = name + " — self-check against the host-synchronised protocol passed", (comm, so, one_call)
                     break
-                failed.append(name.split(" ")[0] + " self-check FAILED")
+                failed.append(name.split(" ")[0] + (" (one call per cycle)" if one_call else "") + " self-check FAILED")
             if chosen is None:
-                chosen = (torch_comm, False)
+                chosen = (torch_comm, False, False)
                 halo_mode = "torch.distributed RCCL, host-synchronised (" + "; ".join(failed) + ")"
             elif failed:
                 halo_mode += " (" + "; ".join(failed) + ")"
             grid.comm = chosen[0]
+            params.native_cycle = chosen[2]
             if chosen[0] is torch_comm:
                 torch_comm.stream_ordered = chosen[1]
             init_test(params, grid, tune=False)

@@ -134,6 +134,7 @@ def test_one_rank_over_real_rccl_runs_both_workloads_through_the_native_cycle():
                  env={"ARMON_BENCH_FORCE_DIST": "1", "ARMON_BENCH_FORCE_SECOND": "1"})
     assert d["n_gpus"] == 1 and d["config"]["halo_exchange_downgraded"] is False, d["config"]["halo_exchange_error"]
     assert d["config"]["halo_exchange"].startswith("native (armon_hip_halo_exchange over RCCL")
+    assert "whole cycles enqueued by armon_hip_mgpu_cycle" in d["config"]["halo_exchange"]
     assert d["weak"]["value"] > 0 and d["weak"]["halo_exchange_downgraded"] is False
     assert d["self_check"]["mass_drift"] <= 1e-12 and d["weak"]["self_check"]["lines_identical"] is True
     assert set(d["roofline"]["per_kernel_ms"]) == {"sweep_x", "sweep_y"} and d["roofline"]["launches_timed"] == 6
