@@ -138,3 +138,13 @@ def test_one_rank_over_real_rccl_runs_both_workloads_through_the_native_cycle():
     assert d["weak"]["value"] > 0 and d["weak"]["halo_exchange_downgraded"] is False
     assert d["self_check"]["mass_drift"] <= 1e-12 and d["weak"]["self_check"]["lines_identical"] is True
     assert set(d["roofline"]["per_kernel_ms"]) == {"sweep_x", "sweep_y"} and d["roofline"]["launches_timed"] == 6
+
+
+def test_a_hanging_transport_candidate_leaves_the_insurance_line():
+    """A transport that hangs in its self-check (a collective that never completes on a machine nobody has run before) must
+    not cost the line: the workload was timed over the host-synchronised protocol first, the watchdog prints that — downgraded,
+    with the phase it gave up in — and the status says failure."""
+    d = run_line([sys.executable, BENCH, "--cells", "1024", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--timeout", "25"],
+                 env={"ARMON_BENCH_FORCE_DIST": "1", "ARMON_BENCH_HANG_CANDIDATE": "1"}, rc=4)
+    assert d["value"] > 0 and d["config"]["halo_exchange_downgraded"] is True and "INSURANCE" in d["config"]["halo_exchange"]
+    assert "self-check of the transport" in d["config"]["halo_exchange_error"] and "Sod 1024x1024" in d["config"]["workload"]
