@@ -754,7 +754,7 @@ def main():
                          "group; auto (default): rccl, and peer when the rank launch gives no line")
     ap.add_argument("--launch-timeout", type=float, default=1500.,
                     help="seconds a child run started by this process may take before its process group is killed")
-    ap.add_argument("--timeout", type=float, default=900.,
+    ap.add_argument("--timeout", type=float, default=600.,
                     help="seconds the primary workload may take inside a rank before the process gives up (exit status 4)")
     ap.add_argument("--strong", action="store_true", help="(default) the global grid stays --cells² (or --global) whatever the number of GPUs")
     ap.add_argument("--weak", action="store_true", help="weak scaling only: --cells² cells PER GPU is the (single) workload")
