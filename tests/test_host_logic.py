@@ -366,3 +366,36 @@ def test_bench_launcher_helpers_kill_by_process_group_and_find_the_line(tmp_path
                                    [33554432, 33554432, 33554432])
     assert pl[0]["chosen_vs_group_best"] == 1.0 and round(pl[2]["chosen_vs_group_best"], 3) == 1.067 and "chosen_vs_group_best" not in pl[1]
     assert bench.slowest_rank(pl) == 2 and bench.slowest_rank([{"rank": 0, "tries": 0}]) is None and bench.slowest_rank(None) is None
+
+
+def test_cycle_plan_follows_split_axes(monkeypatch):
+    """multi_tile.cycle_plan = the armon_cycle_plan of one solver cycle: the sweeps of split_axes (ref src/axis_splitting.jl:
+    24-46) with their steps current_dt x factor, the last cycle's emit_p, cst_dt's missing reduction, the NEXT cycle's first
+    axis for the exchange posted ahead (it alternates under Godunov / Strang splitting), the landing slot of the next CFL step."""
+    from armon_amd.multi_tile import cycle_plan
+    from armon_amd.solver import DT_EVENT_SLOT, GlobalTimeStep
+
+    class Pinned:
+        ptr = 0x1000
+
+    X, Y = 0, 1
+    for splitting, expect in (("Sequential", {0: ([X, Y], [1, 1], X), 1: ([X, Y], [1, 1], X)}),
+                              ("Godunov", {0: ([X, Y], [1, 1], Y), 1: ([Y, X], [1, 1], X)}),
+                              ("Strang", {0: ([X, Y, X], [.5, 1, .5], Y), 1: ([Y, X, Y], [.5, 1, .5], X)}),
+                              ("Y_only", {0: ([Y], [1], Y), 3: ([Y], [1], Y)})):
+        p = ArmonParameters(test="Sod", N=(64, 64), axis_splitting=splitting)
+        gdt = GlobalTimeStep(p)
+        for cycle, (axes, factors, nxt) in expect.items():
+            gdt.cycle, gdt.current_dt = cycle, 0.25
+            plan, n = cycle_plan(p, gdt, last_cycle=False, dt_host=Pinned())
+            assert n == plan.n_sweeps == len(axes) and list(plan.axis)[:n] == axes
+            assert list(plan.dt)[:n] == [0.25 * f for f in factors]
+            assert plan.next_axis == nxt and plan.emit_p == 0 and plan.emit_dt == 1 and plan.overlap == 1
+            assert plan.dt_host == 0x1000 + 8 * (cycle & 1) and plan.dt_event_slot == DT_EVENT_SLOT + (cycle & 1) and plan.event_slot == -1
+            last, _ = cycle_plan(p, gdt, last_cycle=True, dt_host=Pinned())
+            assert last.emit_p == 1 and last.next_axis == -1
+    p = ArmonParameters(test="Sod", N=(64, 64), cst_dt=True, Dt=1e-3, data_type="float32", overlap_halo=False)
+    gdt = GlobalTimeStep(p)
+    gdt.current_dt = p.T(1e-3)
+    plan, _ = cycle_plan(p, gdt, last_cycle=False, dt_host=Pinned())
+    assert plan.emit_dt == 0 and plan.dt_host is None and plan.dt_event_slot == -1 and plan.overlap == 0 and plan.next_axis == -1
