@@ -98,6 +98,9 @@ inline void range_grid(const armon_range& r, int cells_per_thread, dim3& grid, d
 }
 
 int ensure_partials(armon_ctx* ctx, size_t n);
+// staged_kernels.hip: pack_to_array! / unpack_from_array! of BOTH sides of an axis in one launch (the multi-GPU exchange)
+template <typename T>
+int pack_pair(armon_ctx* ctx, const armon_range r[2], int nghost, int64_t face, T* const array[2], int nvars, T* const* vars, bool pack);
 void disown_graphs(armon_ctx* ctx);      // dt_state.hip
 
 }  // namespace armon

@@ -378,24 +378,36 @@ int start_pack(armon_mgpu* g, size_t k, int axis, const armon_halo_desc* d, bool
         ARMON_HIP_TRY(hipEventRecord(t.e_state, t.ctx->stream));
         ARMON_HIP_TRY(hipStreamWaitEvent(t.xfer, t.e_state, 0));
     }
+    const bool both = t.nb[s0] >= 0 && t.nb[s0 + 1] >= 0;
+    armon_range border[2];
+    int64_t face = 0;
     for (int s = s0; s < s0 + 2; s++) {
         if (t.nb[s] < 0) continue;
-        armon_range border;
-        int64_t face;
-        int rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, &border, nullptr, &face);
+        int rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, &border[s - s0], nullptr, &face);
         if (rc != ARMON_OK) return rc;
-        const size_t bytes = (size_t)face * d[k].nghost * d[k].nvars * sizeof(T);
         // the previous message of this side must have left send[s]: in-process, the neighbour's copy out of it (its event);
         // RCCL: our own send, earlier on this same stream
         if (!g->rccl) {
             tile_t& n = g->tiles[t.nb[s]];
             if (n.rec_recv[opposite(s)]) ARMON_HIP_TRY(hipStreamWaitEvent(pc->stream, n.e_recv[opposite(s)], 0));
         }
-        chaos(g, t, pc->stream);
-        touched = true;
-        rc = pack<T>(pc, border, d[k].nghost, face, static_cast<T*>(t.send[s]), d[k].nvars,
-                     reinterpret_cast<const T* const*>(d[k].vars));
+    }
+    const size_t bytes = (size_t)face * d[k].nghost * d[k].nvars * sizeof(T);
+    chaos(g, t, pc->stream);
+    touched = true;
+    if (both) {
+        // the two faces of the axis in ONE launch
+        T* const arrays[2] = {static_cast<T*>(t.send[s0]), static_cast<T*>(t.send[s0 + 1])};
+        int rc = pack_pair<T>(pc, border, d[k].nghost, face, arrays, d[k].nvars, reinterpret_cast<T* const*>(d[k].vars), true);
         if (rc != ARMON_OK) return rc;
+    }
+    for (int s = s0; s < s0 + 2; s++) {
+        if (t.nb[s] < 0) continue;
+        if (!both) {
+            int rc = pack<T>(pc, border[s - s0], d[k].nghost, face, static_cast<T*>(t.send[s]), d[k].nvars,
+                             reinterpret_cast<const T* const*>(d[k].vars));
+            if (rc != ARMON_OK) return rc;
+        }
         ARMON_HIP_TRY(hipEventRecord(t.e_pack[s], pc->stream));
         t.inflight[s] = bytes;
     }
@@ -480,21 +492,33 @@ int finish_one(armon_mgpu* g, size_t k, int axis, const armon_halo_desc* d, bool
 {
     const int s0 = first_side(axis);
     tile_t& t = g->tiles[k];
+    if (!t.inflight[s0] && !t.inflight[s0 + 1]) return ARMON_OK;
+    const bool both = t.inflight[s0] && t.inflight[s0 + 1];
+    armon_ctx* c = on_edge ? t.edge : t.ctx;
+    armon_range ghost[2];
+    int64_t face = 0;
+    ARMON_HIP_TRY(hipSetDevice(t.device));
     for (int s = s0; s < s0 + 2; s++) {
         if (!t.inflight[s]) continue;
-        armon_range ghost;
-        int64_t face;
-        int rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, nullptr, &ghost, &face);
+        int rc = armon_hip_halo_ranges(d[k].nx, d[k].ny, d[k].nghost, s, nullptr, &ghost[s - s0], &face);
         if (rc != ARMON_OK) return rc;
         ARMON_REQUIRE((size_t)face * d[k].nghost * d[k].nvars * sizeof(T) == t.inflight[s],
                       "tile %zu: finish does not match the exchange that was started", k);
-        ARMON_HIP_TRY(hipSetDevice(t.device));
-        armon_ctx* c = on_edge ? t.edge : t.ctx;
-        chaos(g, t, c->stream);
         if (!on_edge) ARMON_HIP_TRY(hipStreamWaitEvent(c->stream, t.e_recv[s], 0));
-        rc = unpack<T>(c, ghost, d[k].nghost, face, static_cast<const T*>(t.recv[s]), d[k].nvars,
-                       reinterpret_cast<T* const*>(d[k].vars));
+    }
+    chaos(g, t, c->stream);
+    if (both) {                                  // both sides in ONE launch, behind both receives
+        T* const arrays[2] = {static_cast<T*>(t.recv[s0]), static_cast<T*>(t.recv[s0 + 1])};
+        int rc = pack_pair<T>(c, ghost, d[k].nghost, face, arrays, d[k].nvars, reinterpret_cast<T* const*>(d[k].vars), false);
         if (rc != ARMON_OK) return rc;
+    }
+    for (int s = s0; s < s0 + 2; s++) {
+        if (!t.inflight[s]) continue;
+        if (!both) {
+            int rc = unpack<T>(c, ghost[s - s0], d[k].nghost, face, static_cast<const T*>(t.recv[s]), d[k].nvars,
+                               reinterpret_cast<T* const*>(d[k].vars));
+            if (rc != ARMON_OK) return rc;
+        }
         ARMON_HIP_TRY(hipEventRecord(t.e_unpack[s], c->stream));
         t.rec_unpack[s] = true;
         t.inflight[s] = 0;

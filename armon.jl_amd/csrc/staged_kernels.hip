@@ -564,8 +564,8 @@ constexpr int kMaxPackVars = 8;
 template <typename T> struct pack_vars { T* v[kMaxPackVars]; };   // passed by value: no device-side pointer table
 
 template <bool PACK, typename T>
-__global__ void __launch_bounds__(kBlock)
-k_pack(armon_range r, int nghost, int64_t face, T* __restrict__ array, int nvars, pack_vars<T> vars)
+__device__ __forceinline__ void pack_range(const armon_range& r, int nghost, int64_t face, T* __restrict__ array, int nvars,
+                                           const pack_vars<T>& vars)
 {
     const int64_t n = r.col_len * r.row_len;
     for (int64_t itr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; itr < n;
@@ -579,6 +579,24 @@ k_pack(armon_range r, int nghost, int64_t face, T* __restrict__ array, int nvars
             else vars.v[v][idx] = array[i_arr + v];
         }
     }
+}
+
+template <bool PACK, typename T>
+__global__ void __launch_bounds__(kBlock)
+k_pack(armon_range r, int nghost, int64_t face, T* __restrict__ array, int nvars, pack_vars<T> vars)
+{
+    pack_range<PACK, T>(r, nghost, face, array, nvars, vars);
+}
+
+// the two sides of an axis in ONE launch (blockIdx.y = side): what the multi-GPU exchange packs / unpacks per sweep
+// (csrc/multi_gpu.hip) — same layout, one dependent launch less on the transfer stream's chain
+template <bool PACK, typename T>
+__global__ void __launch_bounds__(kBlock)
+k_pack_pair(armon_range r0, armon_range r1, int nghost, int64_t face, T* __restrict__ array0, T* __restrict__ array1, int nvars,
+            pack_vars<T> vars)
+{
+    if (blockIdx.y == 0) pack_range<PACK, T>(r0, nghost, face, array0, nvars, vars);
+    else pack_range<PACK, T>(r1, nghost, face, array1, nvars, vars);
 }
 
 // ---- a16: init_test (ref src/kernels.jl:71-145, src/tests.jl:59-121) -------------------------------
@@ -918,6 +936,35 @@ int init_test_impl(armon_ctx* ctx, armon_range r, int test, int64_t row_length, 
 }
 
 }  // namespace
+
+// Both sides of an axis in one launch, for the exchange of csrc/multi_gpu.hip (declared in common.hpp). The two ranges have
+// the same shape (the low and the high border / ghost domain of one axis).
+namespace armon {
+template <typename T>
+int pack_pair(armon_ctx* ctx, const armon_range r[2], int nghost, int64_t face, T* const array[2], int nvars, T* const* vars, bool pack)
+{
+    ARMON_REQUIRE(ctx && array[0] && array[1] && vars, "NULL argument");
+    ARMON_REQUIRE(nvars > 0 && nvars <= kMaxPackVars && nghost > 0 && face > 0, "invalid nvars / nghost / face");
+    ARMON_REQUIRE(range_ok(r[0]) && range_ok(r[1]) && r[0].col_len == r[1].col_len && r[0].row_len == r[1].row_len &&
+                  r[0].col_len * r[0].row_len <= face * nghost, "the two sides of an axis must have the same, valid shape");
+    if (range_empty(r[0])) return ARMON_OK;
+    pack_vars<T> table = {};
+    for (int v = 0; v < nvars; v++) {
+        ARMON_REQUIRE(vars[v] != nullptr, "NULL array in vars[%d]", v);
+        table.v[v] = vars[v];
+    }
+    dim3 grid, block;
+    linear_grid(ctx, r[0].col_len * r[0].row_len, grid, block);
+    grid.y = 2;
+    if (pack)
+        hipLaunchKernelGGL((k_pack_pair<true, T>), grid, block, 0, ctx->stream, r[0], r[1], nghost, face, array[0], array[1], nvars, table);
+    else
+        hipLaunchKernelGGL((k_pack_pair<false, T>), grid, block, 0, ctx->stream, r[0], r[1], nghost, face, array[0], array[1], nvars, table);
+    return check_launch(pack ? "pack_pair" : "unpack_pair");
+}
+template int pack_pair<double>(armon_ctx*, const armon_range[2], int, int64_t, double* const[2], int, double* const*, bool);
+template int pack_pair<float>(armon_ctx*, const armon_range[2], int, int64_t, float* const[2], int, float* const*, bool);
+}  // namespace armon
 
 // ---- C ABI: every entry point exists for fp64 (reference names) and fp32 (`_f32` suffix) -------------------------
 #define ARMON_EXPORT(name, impl, PARAMS, ARGS)                                            \

@@ -71,9 +71,11 @@ for label, P, N, periodic in (("(a) 1 tile, remote on all 4 sides (periodic 1x1 
         if P == (1, 1) and driver == "native, thread per tile":
             continue
         for pack in (("compute", "xfer") * 2 if args.pack_ab else ("xfer",)):
-            for prio in (("normal", "lowest") * 2 if args.prio_ab else ("lowest",)):
+            for prio in (("normal", "lowest") * 2 if args.prio_ab else (None,)):
                 os.environ["ARMON_MGPU_PACK"] = pack
-                os.environ["ARMON_MGPU_XFER_PRIORITY"] = prio
+                os.environ.pop("ARMON_MGPU_XFER_PRIORITY", None)        # None: the library's own choice (lowest when a tile has its device to itself)
+                if prio:
+                    os.environ["ARMON_MGPU_XFER_PRIORITY"] = prio
                 enq, total = measure(P, N, periodic, driver)
                 print(f"  {label:58s} {driver:26s} {enq:10.4f}        {total:10.4f}" + (f"   packs on {pack}" if args.pack_ab else "")
                       + (f"   transfer stream priority {prio}" if args.prio_ab else ""), flush=True)
@@ -113,9 +115,11 @@ def measure_rank(N, native):
 label = "(c) 1 rank over RCCL, send/recv to itself on all 4 sides"
 for native in (False, True):
     for pack in (("compute", "xfer") * 2 if args.pack_ab else ("xfer",)):
-        for prio in (("normal", "lowest") * 2 if args.prio_ab else ("lowest",)):
+        for prio in (("normal", "lowest") * 2 if args.prio_ab else (None,)):
             os.environ["ARMON_MGPU_PACK"] = pack
-            os.environ["ARMON_MGPU_XFER_PRIORITY"] = prio
+            os.environ.pop("ARMON_MGPU_XFER_PRIORITY", None)
+            if prio:
+                os.environ["ARMON_MGPU_XFER_PRIORITY"] = prio
             enq, total = measure_rank((tx, ty), native)
             print(f"  {label:58s} {'native, calling thread' if native else 'host calls':26s} {enq:10.4f}        {total:10.4f}"
                   + (f"   packs on {pack}" if args.pack_ab else "") + (f"   transfer stream priority {prio}" if args.prio_ab else ""), flush=True)
