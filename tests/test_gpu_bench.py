@@ -98,6 +98,12 @@ def test_peer_transport_drives_every_tile_from_one_process():
                  env={**REHEARSAL, "ARMON_MGPU_THREADS": "0"})
     assert d["n_gpus"] == 4 and "2x2 tiles of 256x256" in d["config"]["workload"] and "weak" not in d
     assert "the calling thread only" in d["config"]["halo_exchange"]
+    # --weak: the weak workload alone (--cells² per GPU) is the line; --global names any other grid
+    d = run_line([sys.executable, BENCH, *SMALL, "--transport", "peer", "--weak"], env=REHEARSAL)
+    assert d["scaling"] == "weak" and "Sod 1024x512" in d["config"]["workload"] and "2x1 tiles of 512x512" in d["config"]["workload"] and "weak" not in d
+    d = run_line([sys.executable, BENCH, "--gpus", "2", "--global", "768x512", "--grid", "1x2", "--steps", "2", "--warmup", "1", "--transport", "peer"],
+                 env=REHEARSAL)
+    assert d["scaling"] == "strong" and "1x2 tiles of 768x256" in d["config"]["workload"] and "weak" not in d
 
 
 def test_failed_rank_launch_falls_back_to_the_peer_transport_loudly():
