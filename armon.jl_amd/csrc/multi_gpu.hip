@@ -23,6 +23,7 @@
 // Buffer layout on the wire = pack_to_array!'s (ref src/halo_exchange.jl:187-216), produced by the same kernels as
 // armon_hip_pack_to_array / armon_hip_unpack_from_array.
 #include "common.hpp"
+#include "tile_pool.hpp"
 
 #include <cmath>
 #include <dlfcn.h>
@@ -138,7 +139,6 @@ struct tile_t {
 
 }  // namespace
 
-struct tile_pool;
 struct armon_mgpu {
     int px = 1, py = 1;
     bool rccl = false;
@@ -714,106 +714,7 @@ int dt_allreduce(armon_mgpu* g, T* const* dt_dev)
 // cost of a cycle stays well under the 0.75 ms of GPU work of the 8-GPU strong-scaling tile (4096 x 8192). A group of
 // several local tiles is driven by one host thread per tile (the HIP runtime serialises a thread's calls; 8 devices fed
 // from one thread cost 8 x the enqueue time): the cycle is a list of steps, a step is executed for tile k by thread k,
-// and a barrier separates two steps — the rule of the per-tile functions above.
-}  // namespace
-
-struct tile_pool {
-    std::vector<std::thread> threads;
-    std::mutex m;
-    std::condition_variable cv_go, cv_done;
-    uint64_t generation = 0;
-    int pending = 0;
-    bool stop = false;
-    const std::vector<std::function<int(size_t)>>* steps = nullptr;
-    std::vector<int> rc;                         // per tile
-    std::vector<std::string> msg;
-    std::atomic<int> failed{0};
-    std::atomic<int> bar_count{0};
-    std::atomic<int> bar_sense{0};
-    int n = 0;
-
-    void barrier(int& local_sense)
-    {
-        local_sense ^= 1;
-        if (bar_count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
-            bar_count.store(0, std::memory_order_relaxed);
-            bar_sense.store(local_sense, std::memory_order_release);
-        } else {
-            int spins = 0;
-            while (bar_sense.load(std::memory_order_acquire) != local_sense)
-                if (++spins > 2000) std::this_thread::yield();
-        }
-    }
-
-    void run_tile(size_t k, int& local_sense)
-    {
-        for (const auto& step : *steps) {
-            if (!failed.load(std::memory_order_acquire)) {
-                int r = step(k);
-                if (r != ARMON_OK) {
-                    rc[k] = r;
-                    msg[k] = armon_hip_last_error();
-                    failed.store(1, std::memory_order_release);
-                }
-            }
-            barrier(local_sense);
-        }
-    }
-
-    void worker(size_t k)
-    {
-        uint64_t seen = 0;
-        int local_sense = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv_go.wait(lk, [&] { return stop || generation != seen; });
-                if (stop) return;
-                seen = generation;
-            }
-            run_tile(k, local_sense);
-            {
-                std::lock_guard<std::mutex> lk(m);
-                if (--pending == 0) cv_done.notify_one();
-            }
-        }
-    }
-
-    explicit tile_pool(int n_tiles) : rc(n_tiles, ARMON_OK), msg(n_tiles), n(n_tiles)
-    {
-        for (int k = 0; k < n_tiles; k++) threads.emplace_back([this, k] { worker((size_t)k); });
-    }
-
-    ~tile_pool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m);
-            stop = true;
-        }
-        cv_go.notify_all();
-        for (auto& t : threads) t.join();
-    }
-
-    int run(const std::vector<std::function<int(size_t)>>& s)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        steps = &s;
-        failed.store(0);
-        for (int k = 0; k < n; k++) rc[k] = ARMON_OK;
-        pending = n;
-        generation++;
-        cv_go.notify_all();
-        cv_done.wait(lk, [&] { return pending == 0; });
-        for (int k = 0; k < n; k++)
-            if (rc[k] != ARMON_OK) {
-                set_error("tile %d: %s", k, msg[k].c_str());
-                return rc[k];
-            }
-        return ARMON_OK;
-    }
-};
-
-namespace {
+// and a barrier separates two steps — the rule of the per-tile functions above (the threads: tile_pool.hpp).
 
 template <typename T> struct cycle_traits;
 template <> struct cycle_traits<double> {
@@ -855,8 +756,12 @@ bool want_threads(armon_mgpu* g)
 int run_steps(armon_mgpu* g, const std::vector<std::function<int(size_t)>>& steps)
 {
     if (want_threads(g)) {
-        if (!g->pool) g->pool = new tile_pool((int)g->tiles.size());
-        return g->pool->run(steps);
+        if (!g->pool) g->pool = new tile_pool((int)g->tiles.size(), [] { return std::string(armon_hip_last_error()); });
+        int tile = -1;
+        std::string message;
+        const int rc = g->pool->run(steps, &tile, &message);
+        if (rc != ARMON_OK) set_error("tile %d: %s", tile, message.c_str());
+        return rc;
     }
     for (const auto& step : steps)
         for (size_t k = 0; k < g->tiles.size(); k++) {
