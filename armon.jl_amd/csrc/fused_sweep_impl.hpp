@@ -17,7 +17,7 @@
 // Redundant work is confined to the LAG (≤4) cells at both ends of a run / strip. Block and strip origins are
 // aligned to the 64-B sectors of the ghosted rows, stores are non-temporal (profiles/NOTES.md has the A/B numbers).
 // Tuning knobs (tools/ab_sweep.py, parity tests), read from the environment once per context or set with
-// armon_hip_set_tuning: ARMON_SWEEP_ALIGN, ARMON_XS_NITER, ARMON_Y_SEG, ARMON_Y_COLS1; compile-time: ARMON_NT,
+// armon_hip_set_tuning: ARMON_SWEEP_ALIGN, ARMON_XS_NITER, ARMON_Y_SEG, ARMON_Y_COLS1; compile-time: ARMON_NT_X, ARMON_NT_Y,
 // ARMON_Y_PF, ARMON_Y_WAVES, ARMON_Y_BLOCK, ARMON_PROBE_NOCOMPUTE, ARMON_ONLY_HEADLINE.
 #pragma once
 #include "common.hpp"
@@ -46,24 +46,44 @@ namespace {
 using real = ARMON_SWEEP_REAL;
 using vec2 = std::conditional<std::is_same<real, double>::value, double2, float2>::type;
 
-// Streaming hints (tuning macros, see tools/build_variant.sh): the state is read once and written once per
-// sweep and is far larger than L2 + MALL, so `nt` keeps it from displacing the halo rows/columns that ARE
-// re-read. Bit 0 of ARMON_NT: loads, bit 1: stores.
-#ifndef ARMON_NT
-#define ARMON_NT 2
+// Streaming hints (tuning macros, see tools/build_variant.sh): the state is read once and written once per sweep and is far
+// larger than L2 + MALL. Bit 0: `nt` loads, bit 1: `nt` stores; one macro per sweep kernel family, because they answer
+// differently (profiles/r05_ab_nt.txt, launches interleaved in one process):
+//  * ARMON_NT_X (the X sweep's 16-B global loads / stores): 3. Non-temporal LOADS too since round 5 — for the flavour they
+//    pay for, the tuned fp64 perfect-gas sweep (x_nt_loads below): 2.755 -> 2.68-2.72 ms at 16384², 0.682 -> 0.666 at 8192²,
+//    0.342 -> 0.330 at 4096 x 8192, every size 2.4-3.8 % — a strip is read once by one wave, and lines that are not kept do not
+//    push the rest out. The same hint costs the Bizarrium sweep 2.4 % and the fp32 one 3.3 % (their waves hold their loads
+//    longer / share lines inside the workgroup) and does nothing for the exact flavour: they keep ordinary loads.
+//  * ARMON_NT_Y (the Y march's buffer loads / stores): 2. Its runs re-read 2·LAG halo rows that the run below has just
+//    loaded: with `nt` loads they are gone (+4 % at 16384² with nt stores, +21 % without).
+#ifdef ARMON_NT
+#define ARMON_NT_X ARMON_NT
+#define ARMON_NT_Y ARMON_NT
+#endif
+#ifndef ARMON_NT_X
+#define ARMON_NT_X 3
+#endif
+#ifndef ARMON_NT_Y
+#define ARMON_NT_Y 2
 #endif
 typedef real vreal2 __attribute__((ext_vector_type(2)));
+template <bool NT = false>
 __device__ __forceinline__ vec2 ld2(const real* p)
 {
     const vreal2* q = reinterpret_cast<const vreal2*>(p);
-    const vreal2 v = (ARMON_NT & 1) ? __builtin_nontemporal_load(q) : *q;
+    const vreal2 v = NT ? __builtin_nontemporal_load(q) : *q;
     return vec2{v.x, v.y};
+}
+// which instantiations of the X sweep load their strips non-temporally (see ARMON_NT_X above)
+constexpr bool x_nt_loads(int eos, bool exact)
+{
+    return (ARMON_NT_X & 1) && sizeof(real) == 8 && eos == ARMON_EOS_PERFECT_GAS && !exact;
 }
 __device__ __forceinline__ void st2(real* p, real x, real y)
 {
     vreal2* q = reinterpret_cast<vreal2*>(p);
     const vreal2 v = {x, y};
-    if (ARMON_NT & 2) __builtin_nontemporal_store(v, q);
+    if (ARMON_NT_X & 2) __builtin_nontemporal_store(v, q);
     else *q = v;
 }
 
@@ -147,7 +167,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
 }
-constexpr int kAuxLoad = (ARMON_NT & 1) ? 2 : 0, kAuxStore = (ARMON_NT & 2) ? 2 : 0;   // gfx950 cache policy: bit 1 = nt
+constexpr int kAuxLoad = (ARMON_NT_Y & 1) ? 2 : 0, kAuxStore = (ARMON_NT_Y & 2) ? 2 : 0;   // gfx950 cache policy: bit 1 = nt
 template <typename T> __device__ __forceinline__ T buf_load(rsrc_t r, unsigned voff, unsigned soff);
 template <>
 __device__ __forceinline__ double buf_load<double>(rsrc_t r, unsigned voff, unsigned soff)
@@ -720,10 +740,11 @@ __device__ __forceinline__ void sweep_x_dpp_body(const sweep_args& a, int niter)
         const bool interior = cb >= 0 && cb + WIDTH <= a.nx;          // uniform: no ghost, no clamping
         if (interior && (K == 1 || vec_ok)) {
             if (K == 2) {
-                const vec2 r = ld2(in[0] + j0);
-                const vec2 u = ld2(in[1] + j0);
-                const vec2 v = ld2(in[2] + j0);
-                const vec2 e = ld2(in[3] + j0);
+                constexpr bool NT = x_nt_loads(EOS, EXACT);
+                const vec2 r = ld2<NT>(in[0] + j0);
+                const vec2 u = ld2<NT>(in[1] + j0);
+                const vec2 v = ld2<NT>(in[2] + j0);
+                const vec2 e = ld2<NT>(in[3] + j0);
                 rho.v[0] = r.x; rho.v[K - 1] = r.y;
                 ua.v[0] = u.x; ua.v[K - 1] = u.y;
                 ut.v[0] = v.x; ut.v[K - 1] = v.y;
