@@ -167,7 +167,14 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
 }
-constexpr int kAuxLoad = (ARMON_NT_Y & 1) ? 2 : 0, kAuxStore = (ARMON_NT_Y & 2) ? 2 : 0;   // gfx950 cache policy: bit 1 = nt
+// gfx950 cache policy of a buffer access: bit 0 = sc0, bit 1 = nt, bit 4 = sc1 (ARMON_Y_AUX_LD / _ST: raw values, A/B builds)
+#ifndef ARMON_Y_AUX_LD
+#define ARMON_Y_AUX_LD ((ARMON_NT_Y & 1) ? 2 : 0)
+#endif
+#ifndef ARMON_Y_AUX_ST
+#define ARMON_Y_AUX_ST ((ARMON_NT_Y & 2) ? 2 : 0)
+#endif
+constexpr int kAuxLoad = ARMON_Y_AUX_LD, kAuxStore = ARMON_Y_AUX_ST;
 template <typename T> __device__ __forceinline__ T buf_load(rsrc_t r, unsigned voff, unsigned soff);
 template <>
 __device__ __forceinline__ double buf_load<double>(rsrc_t r, unsigned voff, unsigned soff)
