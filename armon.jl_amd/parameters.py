@@ -233,7 +233,7 @@ class ArmonParameters:
 
     # ref src/parameters.jl:766-778 — backend specific options (like ext/ArmonKokkos.jl:83-87)
     def _init_backend(self, device_id=None, use_fused_sweep=True, exact_arithmetic=False, stream=None,
-                      placement_tries=16, stream_ordered_halo=True, ctx=None, native_halo=True, overlap_halo=True, edge_stream=True,
+                      placement_tries=24, stream_ordered_halo=True, ctx=None, native_halo=True, overlap_halo=True, edge_stream=True,
                       placement_min_bytes=256 << 20, placement_rounds=8, graph_cycles=False, native_cycle=True, **options):
         """``device_id``: GPU ordinal (default LOCAL_RANK or 0). ``use_fused_sweep``: run each sweep as
         the fused HIP kernel instead of the 5 staged kernels. ``exact_arithmetic=True``: IEEE division/sqrt

@@ -259,7 +259,7 @@ class BlockGrid:
                                                       C.byref(picks), times))
                 else:
                     check(params.fn("choose_placement")(dev.ctx, C.byref(d_x), C.byref(d_y), ptrs, len(pool), nbytes,
-                                                        tries, 0.01, C.byref(picks), times, C.byref(done)))
+                                                        tries, 0.004, C.byref(picks), times, C.byref(done)))
             except _lib.SolverException:          # e.g. no room for the 4 transient vectors: nothing was moved in THIS round
                 # pool[:8] is the assignment this round started from — the grid's own vectors in round 1, the best of the
                 # previous rounds afterwards (the grid's original vectors may then be among the losers): install it before
