@@ -206,7 +206,7 @@ class BlockGrid:
         memory = the 8 ``spare`` vectors only (17 GB at 16384²). The pool is deliberately small: among 12-16 vectors
         allocated one after the other about half of the random draws land on the fast level, among 32 one in twenty
         (profiles/r02_placement_pool_sizes.txt). A pool is either slow for EVERY assignment or fast for most of them
-        (profiles/r02_placement_what_it_is_not.txt), so a round is short — ``placement_tries`` = 16 draws — and a round
+        (profiles/r02_placement_what_it_is_not.txt), so a round is short — ``placement_tries`` = 24 draws at most, 12 when two of them already lie within 0.4 % of the best — and a round
         that found nothing is followed by a fresh batch of spares, up to ``placement_rounds`` = 8 times.
         ``keep_state=True``: ``armon_hip_tune_placement`` moves a LIVE state around (4 more vectors park it meanwhile). ~20 ms per try, outside any timed region.
         Returns the report also stored in ``self.placement``."""
