@@ -32,6 +32,7 @@ struct armon_ctx {
     int tune_y_cols1 = 0;            // ARMON_Y_COLS1: fp32 Y march with one column per lane
     int tune_x_xcd = -1;             // ARMON_X_XCD: XCD-aware workgroup placement in the X sweep (-1 = by precision: fp64 on, fp32 off)
     int tune_x_rows = 0;             // ARMON_X_ROWS: workgroup of the X sweep = 1: one strip of 4 rows, 2: 4 strips of one row, 0: by precision
+    int tune_copy_nt = 0;            // ARMON_COPY_NT: the measurement aid armon_hip_stream_copy4 with nt loads (bit 0) / stores (bit 1)
     int tune_y_sx = 0;               // ARMON_Y_SX: store exchange of the Y march = 1: always, 2: never, 0: when the row pitch is not a multiple of a sector
     // y_run_length's last answer (it depends on the shape only)
     int64_t seg_nx = -1, seg_ny = -1;

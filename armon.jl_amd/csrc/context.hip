@@ -102,7 +102,7 @@ int armon_hip_init(int device_id, void* stream, armon_ctx** out)
     }
     int rc = ensure_partials(ctx, 8192);
     if (rc != ARMON_OK) { armon_hip_destroy(ctx); return rc; }
-    for (const char* knob : {"ARMON_XS_NITER", "ARMON_Y_SEG", "ARMON_SWEEP_ALIGN", "ARMON_Y_COLS1", "ARMON_X_XCD", "ARMON_X_ROWS", "ARMON_Y_SX"}) {
+    for (const char* knob : {"ARMON_XS_NITER", "ARMON_Y_SEG", "ARMON_SWEEP_ALIGN", "ARMON_Y_COLS1", "ARMON_X_XCD", "ARMON_X_ROWS", "ARMON_Y_SX", "ARMON_COPY_NT"}) {
         const char* v = getenv(knob);
         if (v && *v) (void)armon_hip_set_tuning(ctx, knob, atoi(v));
     }
@@ -120,6 +120,7 @@ int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value)
     else if (!strcmp(knob, "ARMON_X_XCD")) ctx->tune_x_xcd = value < 0 ? -1 : (value > 0);
     else if (!strcmp(knob, "ARMON_X_ROWS")) ctx->tune_x_rows = (value == 1 || value == 2) ? value : 0;
     else if (!strcmp(knob, "ARMON_Y_SX")) ctx->tune_y_sx = (value == 1 || value == 2) ? value : 0;
+    else if (!strcmp(knob, "ARMON_COPY_NT")) ctx->tune_copy_nt = value & 3;
     else ARMON_REQUIRE(false, "unknown tuning knob '%s'", knob);
     return ARMON_OK;
 }
@@ -134,6 +135,7 @@ int armon_hip_get_tuning(armon_ctx* ctx, const char* knob, int* value)
     else if (!strcmp(knob, "ARMON_X_XCD")) *value = ctx->tune_x_xcd;
     else if (!strcmp(knob, "ARMON_X_ROWS")) *value = ctx->tune_x_rows;
     else if (!strcmp(knob, "ARMON_Y_SX")) *value = ctx->tune_y_sx;
+    else if (!strcmp(knob, "ARMON_COPY_NT")) *value = ctx->tune_copy_nt;
     else if (!strcmp(knob, "Y_RUN_ROWS")) *value = ctx->tune_y_seg > 0 ? ctx->tune_y_seg : ctx->seg_value;
     else ARMON_REQUIRE(false, "unknown tuning knob '%s'", knob);
     return ARMON_OK;
@@ -265,20 +267,35 @@ int armon_hip_memset(armon_ctx* ctx, void* dst, int byte_value, size_t bytes)
     return ARMON_OK;
 }
 
+}  // extern "C"
+
 namespace {
 struct copy4_args { const double2* in[4]; double2* out[4]; };
 
+typedef double vdouble2 __attribute__((ext_vector_type(2)));
+// NT bit 0: non-temporal loads, bit 1: non-temporal stores (ARMON_COPY_NT, armon_hip_set_tuning; the measurement aid takes the
+// fastest form the device has, so that "the same-device copy" stays a ceiling: profiles/r05_ab_nt.txt)
+template <int NT>
 __global__ void __launch_bounds__(256) k_stream_copy4(copy4_args p, size_t n2)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n2) return;
-    double2 v[4];
+    vdouble2 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = p.in[k][i];
+    for (int k = 0; k < 4; k++) {
+        const vdouble2* q = reinterpret_cast<const vdouble2*>(p.in[k] + i);
+        v[k] = (NT & 1) ? __builtin_nontemporal_load(q) : *q;
+    }
 #pragma unroll
-    for (int k = 0; k < 4; k++) p.out[k][i] = v[k];
+    for (int k = 0; k < 4; k++) {
+        vdouble2* q = reinterpret_cast<vdouble2*>(p.out[k] + i);
+        if (NT & 2) __builtin_nontemporal_store(v[k], q);
+        else *q = v[k];
+    }
 }
 }  // namespace
+
+extern "C" {
 
 int armon_hip_stream_copy4(armon_ctx* ctx, const void* const in[4], void* const out[4], size_t bytes)
 {
@@ -292,7 +309,13 @@ int armon_hip_stream_copy4(armon_ctx* ctx, const void* const in[4], void* const 
         p.out[k] = static_cast<double2*>(out[k]);
     }
     const size_t n2 = bytes / 16;
-    hipLaunchKernelGGL(k_stream_copy4, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream, p, n2);
+    const dim3 grid((unsigned)((n2 + 255) / 256)), block(256);
+    switch (ctx->tune_copy_nt & 3) {
+    case 0: hipLaunchKernelGGL(k_stream_copy4<0>, grid, block, 0, ctx->stream, p, n2); break;
+    case 1: hipLaunchKernelGGL(k_stream_copy4<1>, grid, block, 0, ctx->stream, p, n2); break;
+    case 2: hipLaunchKernelGGL(k_stream_copy4<2>, grid, block, 0, ctx->stream, p, n2); break;
+    default: hipLaunchKernelGGL(k_stream_copy4<3>, grid, block, 0, ctx->stream, p, n2);
+    }
     return check_launch("stream_copy4");
 }
 

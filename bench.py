@@ -223,6 +223,25 @@ def slowest_rank(placement):
     return max(known, key=lambda pl: pl["chosen_vs_group_best"])["rank"] if known else None
 
 
+def best_stream_copy(device, src, dst, nb):
+    """The same-device ceiling: the 4-in / 4-out copy of the sweeps' bytes in its two useful forms — plain, and with
+    non-temporal loads and stores (the faster one depends on the size and the placement, profiles/r05_ab_nt.txt) — the better
+    median of 5 launches after 2 warm-up launches each. GB/s."""
+    import armon_amd
+    best = 0.0
+    for nt in (0, 3):
+        armon_amd.lib().armon_hip_set_tuning(device.ctx, b"ARMON_COPY_NT", nt)
+        ms = []
+        for k in range(7):
+            device.event_record(1000)
+            device.stream_copy4(src, dst, nb)
+            device.event_record(1001)
+            ms.append(device.event_elapsed_ms(1000, 1001))
+        best = max(best, 8 * nb / (sorted(ms[2:])[len(ms[2:]) // 2] * 1e-3) / 1e9)
+    armon_amd.lib().armon_hip_set_tuning(device.ctx, b"ARMON_COPY_NT", 0)
+    return best
+
+
 def lines_check(test, rho):
     """For the test cases that vary along one axis only: (every row / column of this tile's density identical and finite,
     the waves have left the initial two states on this tile)."""
@@ -459,13 +478,7 @@ def run_workload(args, dist, world, rank, local_rank, P, N_global, scaling, live
         from armon_amd.solver import STATE_VARS
         src, dst = [grid.data[f] for f in STATE_VARS], [grid.alt[f] for f in STATE_VARS]
         nb = src[0].nbytes & ~15
-        ms = []
-        for k in range(7):
-            params.device.event_record(1000)
-            params.device.stream_copy4(src, dst, nb)
-            params.device.event_record(1001)
-            ms.append(params.device.event_elapsed_ms(1000, 1001))
-        copy_gbps = 8 * nb / (sorted(ms[2:])[len(ms[2:]) // 2] * 1e-3) / 1e9
+        copy_gbps = best_stream_copy(params.device, src, dst, nb)
 
     placement = grid.placement
     if dist is not None:                      # every rank draws its own placement: report them all (the slowest sets the pace)
@@ -581,13 +594,7 @@ def run_peer_workload(args, n_dev, P, N_global, device_ids, primary=True, live_t
         if primary and g0.alt is not None:
             src, dst = [g0.data[f] for f in S.STATE_VARS], [g0.alt[f] for f in S.STATE_VARS]
             nb = src[0].nbytes & ~15
-            ms = []
-            for k in range(7):
-                root.device.event_record(1000)
-                root.device.stream_copy4(src, dst, nb)
-                root.device.event_record(1001)
-                ms.append(root.device.event_elapsed_ms(1000, 1001))
-            copy_gbps = 8 * nb / (sorted(ms[2:])[len(ms[2:]) // 2] * 1e-3) / 1e9
+            copy_gbps = best_stream_copy(root.device, src, dst, nb)
         placement = annotate_placements([dict(rank=r, **(g.placement or {"tries": 0})) for r, g in enumerate(group.grids)], sizes)
         cells_local, cells_total = sizes[0], N_global[0] * N_global[1]
         sweeps = 2 * args.steps

@@ -99,7 +99,8 @@ ARMON_API void* armon_hip_stream(armon_ctx* ctx);                              /
  * workgroups share their lines themselves), "ARMON_X_ROWS" workgroup shape of the X sweep: 1 = one strip of
  * 4 rows, 2 = 4 consecutive strips of one row, 0 = automatic (the former for fp64, the latter for fp32),
  * "ARMON_Y_SX" store exchange of the Y march (rows stored in sector-aligned windows handed over through LDS): 1 = always,
- * 2 = never, 0 = automatic (when the row pitch is not a multiple of a 64-B sector).
+ * 2 = never, 0 = automatic (when the row pitch is not a multiple of a 64-B sector), "ARMON_COPY_NT" the measurement aid
+ * armon_hip_stream_copy4 with non-temporal loads (bit 0) / stores (bit 1).
  * None of them changes a result bit. */
 ARMON_API int armon_hip_set_tuning(armon_ctx* ctx, const char* knob, int value);
 /* the current value of a knob; and, read-only, "Y_RUN_ROWS": rows per run the last automatic choice of the Y march took (0

@@ -94,9 +94,14 @@ def test_stream_copy4(dev):
     src = [rng.random(4098) for _ in range(4)]
     d_src = [dev.from_host(a) for a in src]
     d_dst = [dev.zeros(4098) for _ in range(4)]
-    dev.stream_copy4(d_src, d_dst, src[0].nbytes)
-    for a, d in zip(src, d_dst):
-        assert np.array_equal(d.to_host(), a)
+    import armon_amd
+    for nt in (0, 1, 2, 3):                          # plain / non-temporal loads / stores / both (ARMON_COPY_NT)
+        for d in d_dst:
+            d.fill_bytes(0) if hasattr(d, "fill_bytes") else d.copy_from_host(np.zeros(4098))
+        assert armon_amd.lib().armon_hip_set_tuning(dev.ctx, b"ARMON_COPY_NT", nt) == 0 and dev.get_tuning("ARMON_COPY_NT") == nt
+        dev.stream_copy4(d_src, d_dst, src[0].nbytes)
+        for a, d in zip(src, d_dst):
+            assert np.array_equal(d.to_host(), a), nt
     with pytest.raises(Exception):
         dev.stream_copy4(d_src, d_dst, 24)          # not a multiple of 16
 
