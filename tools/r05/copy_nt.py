@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The measurement aid armon_hip_stream_copy4 (the same-device ceiling bench.py reports) in its four forms — ARMON_COPY_NT bit 0: non-temporal
+loads, bit 1: non-temporal stores — interleaved launch by launch, at 16384² and on the 4096 x 8192 tile.   python tools/r05/copy_nt.py"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import armon_amd, ctypes as C
